@@ -1,0 +1,14 @@
+"""gpmp2_amd -- MI355X-native GPMP2 linearize-and-solve engine (host-side Python mirror).
+
+The compute path is the HIP library gpmp2_amd/csrc/libgpmp2mi.so behind the C ABI of
+include/gpmp2mi.h; this package is the reference-shaped façade over it (robots, SDFs, settings,
+BatchTrajOptimize*, factor evaluateError) used by tests and bench.py.
+"""
+from .datasets import (generate2Ddataset, generate3Ddataset, sdf3_zyx, signedDistanceField2D,  # noqa: F401
+                       signedDistanceField3D)
+from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pose2MobileArm,  # noqa: F401
+                     Pose2MobileArmModel, Pose2MobileBase, Pose2MobileBaseModel, generateArm,
+                     generateMobileArm, generatePointRobot, pose3, rot_yaw)
+from .settings import TrajOptimizerSetting  # noqa: F401
+
+__all__ = [n for n in dir() if not n.startswith("_")]

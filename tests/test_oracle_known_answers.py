@@ -1,0 +1,252 @@
+"""Pins the CPU oracle against every known-answer value the reference's own unit tests hold for
+the hot path, at the reference's own tolerances, plus the
+numerical-Jacobian checks those tests perform (pattern A of SURVEY.md section 4)."""
+import math
+
+import numpy as np
+import pytest
+
+import gpmp2_amd as g
+from helpers import arm_from_golden, num, numeric_jacobian, sdf_to_err, vec
+
+
+# ------------------------------------------------------------------ SDF (testSignedDistanceField.cpp)
+def test_sdf3d_trilinear_and_gradient(oracle, golden):
+    d = golden["sdf3d"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["slices"]))
+    for q in d["queries"]:
+        dist, _, inr = oracle.sdf_query(s, [q["point"]])
+        assert inr[0] == 1
+        assert abs(dist[0] - q["value"]) <= q["tol"]
+    for p in d["gradient_points"]:
+        _, grad, _ = oracle.sdf_query(s, [p])
+        gnum = numeric_jacobian(lambda x: oracle.sdf_query(s, [x])[0][0], p, 1e-6)
+        np.testing.assert_allclose(grad[0], gnum, atol=d["gradient_tol"])
+
+
+def test_sdf2d_bilinear_and_gradient(oracle, golden):
+    d = golden["sdf2d"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["data"]))
+    for q in d["queries"]:
+        dist, _, _ = oracle.sdf_query(s, [q["point"]])
+        assert abs(dist[0] - q["value"]) <= q["tol"]
+    for p in d["gradient_points"]:
+        _, grad, _ = oracle.sdf_query(s, [p])
+        gnum = numeric_jacobian(lambda x: oracle.sdf_query(s, [x])[0][0], p, 1e-6)
+        np.testing.assert_allclose(grad[0], gnum, atol=d["gradient_tol"])
+
+
+def test_sdf_out_of_range_and_upper_face(oracle, golden):
+    d = golden["sdf3d"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["slices"]))
+    # SignedDistanceField.h:103-110: strictly-below origin or strictly-above the last cell throws
+    dist, grad, inr = oracle.sdf_query(s, [[-0.21, 0, 0], [0.21, 0, 0], [0, 0, 0.11], [0, 0, -0.1]])
+    assert list(inr) == [0, 0, 0, 1]
+    assert np.all(dist[:3] == 0) and np.all(grad[:3] == 0)
+    # point exactly on the upper face passes the range check (quirk A.4); weight of the
+    # one-past-the-end corner is 0 so the value is the face value.  Use exactly representable data.
+    s2 = oracle.sdf([0.0, 0.0, 0.0], 1.0, np.arange(27, dtype=float).reshape(3, 3, 3))
+    dist, _, inr = oracle.sdf_query(s2, [[2.0, 2.0, 2.0], [2.0, 1.0, 0.5]])
+    assert list(inr) == [1, 1]
+    assert dist[0] == 26.0            # data[z=2][y=2][x=2]
+    assert dist[1] == 0.5 * (5 + 14)  # between z=0 and z=1 at y=1, x=2
+
+
+# ------------------------------------------------------------------ Arm FK (testArm.cpp)
+def _yaw_pose(yaw, xyz):
+    return g.pose3(g.rot_yaw(yaw), xyz)
+
+
+def test_arm_fk_two_link(oracle, golden):
+    d = golden["arm_fk"]["two_link"]
+    arm = g.ArmModel(g.Arm(2, d["a"], d["alpha"], d["d"], _yaw_pose(num(d["base_yaw"]), d["base_xyz"])), [])
+    r = oracle.robot(arm)
+    for c in d["cases"]:
+        poses, _ = oracle.forward_kinematics(r, vec(c["q"]))
+        for l in range(2):
+            np.testing.assert_allclose(poses[0, l], _yaw_pose(num(c["yaw"][l]), c["xyz"][l]), atol=c["tol"])
+
+
+def test_arm_fk_three_link_and_wam_positions(oracle, golden):
+    d = golden["arm_fk"]["three_link"]
+    r = oracle.robot(g.ArmModel(g.Arm(3, d["a"], d["alpha"], d["d"]), []))
+    poses, _ = oracle.forward_kinematics(r, d["q"])
+    np.testing.assert_allclose(poses[0, :, :3, 3], np.array(d["xyz"]), atol=d["tol"])
+    w = golden["arm_fk"]["wam"]
+    r = oracle.robot(g.ArmModel(g.Arm(7, w["a"], vec(w["alpha"]), w["d"]), []))
+    poses, _ = oracle.forward_kinematics(r, w["q"])
+    np.testing.assert_allclose(poses[0, :, :3, 3], np.array(w["xyz"]), atol=w["tol"])
+
+
+def _pose_local(T0, T1):
+    """gtsam Pose3 localCoordinates (Logmap of T0^-1 T1) to first order, order [omega; v] -- enough
+    for central differences at h = 1e-6."""
+    D = np.linalg.inv(T0) @ T1
+    W = 0.5 * (D[:3, :3] - D[:3, :3].T)
+    return np.array([W[2, 1], W[0, 2], W[1, 0], D[0, 3], D[1, 3], D[2, 3]])
+
+
+@pytest.mark.parametrize("which", ["two_link", "three_link", "wam"])
+def test_arm_pose_jacobians_numeric(oracle, golden, which):
+    d = golden["arm_fk"][which]
+    if which == "two_link":
+        arm = g.Arm(2, d["a"], d["alpha"], d["d"], _yaw_pose(num(d["base_yaw"]), d["base_xyz"]))
+        q = vec(d["cases"][1]["q"])
+    else:
+        arm = g.Arm(len(d["a"]), d["a"], vec(d["alpha"]), d["d"])
+        q = vec(d["q"])
+    r = oracle.robot(g.ArmModel(arm, []))
+    poses, J = oracle.forward_kinematics(r, q)
+    h = 1e-6
+    for l in range(arm.dof()):
+        Jn = np.zeros((6, arm.dof()))
+        for k in range(arm.dof()):
+            dq = np.zeros_like(q)
+            dq[k] = h
+            Pp, _ = oracle.forward_kinematics(r, q + dq)
+            Pm, _ = oracle.forward_kinematics(r, q - dq)
+            Jn[:, k] = (_pose_local(poses[0, l], Pp[0, l]) - _pose_local(poses[0, l], Pm[0, l])) / (2 * h)
+        np.testing.assert_allclose(J[0, l], Jn, atol=golden["arm_fk"]["jacobian_tol"])
+
+
+# ------------------------------------------------------------------ sphere centres (testArmModel.cpp)
+def test_arm_model_sphere_centers(oracle, golden):
+    d = golden["arm_model"]
+    arm = g.Arm(2, d["a"], d["alpha"], d["d"], g.pose3(t=d["base_xyz"]))
+    model = g.ArmModel(arm, [g.BodySphere(int(s[0]), s[1], s[2:5]) for s in d["spheres"]])
+    r = oracle.robot(model)
+    for c in d["cases"]:
+        q = vec(c["q"])
+        ctr, J = oracle.sphere_centers(r, q)
+        np.testing.assert_allclose(ctr[0], np.array(c["centers"]), atol=1e-9)
+        Jn = numeric_jacobian(lambda x: oracle.sphere_centers(r, x)[0][0], q, 1e-6)
+        np.testing.assert_allclose(J[0], Jn, atol=d["jacobian_tol"])
+
+
+def test_point_robot(oracle, golden):
+    d = golden["point_robot"]
+    r = oracle.robot(g.generatePointRobot(1.5))
+    poses, J = oracle.forward_kinematics(r, d["q"])
+    np.testing.assert_allclose(poses[0, 0], g.pose3(t=d["pose_xyz"]), atol=1e-12)
+    ctr, Jc = oracle.sphere_centers(r, d["q"])
+    np.testing.assert_allclose(ctr[0, 0], d["sphere_center"], atol=1e-12)
+    Jn = numeric_jacobian(lambda x: oracle.sphere_centers(r, x)[0][0], d["q"], 1e-6)
+    np.testing.assert_allclose(Jc[0], Jn, atol=1e-9)
+
+
+# ------------------------------------------------------------------ obstacle factors
+def test_obstacle_sdf_factor_arm(oracle, golden):
+    d = golden["obstacle_sdf_factor_arm"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["slices"]))
+    r = oracle.robot(arm_from_golden(d))
+    rad = d["spheres"][0][1]
+    for c in d["unary_cases"]:
+        q = vec(c["q"])
+        err, H = oracle.obstacle_factor(r, s, d["epsilon"], q)
+        np.testing.assert_allclose(err[0], sdf_to_err(c["sdf_expected"], d["epsilon"] + rad), atol=d["tol"])
+        Hn = numeric_jacobian(lambda x: oracle.obstacle_factor(r, s, d["epsilon"], x)[0][0], q, 1e-6)
+        np.testing.assert_allclose(H[0], Hn, atol=d["tol"])
+
+
+def test_obstacle_sdf_factor_gp_arm(oracle, golden):
+    d = golden["obstacle_sdf_factor_arm"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["slices"]))
+    r = oracle.robot(arm_from_golden(d))
+    rad, gp = d["spheres"][0][1], d["gp"]
+    for c in d["gp_cases"]:
+        a = [vec(c[k]) for k in ("q1", "qdot1", "q2", "qdot2")]
+        err, H = oracle.obstacle_gp_factor(r, s, d["epsilon"], None, gp["delta_t"], gp["tau"], *a)
+        np.testing.assert_allclose(err[0], sdf_to_err(c["sdf_expected"], d["epsilon"] + rad), atol=d["tol"])
+        for k in range(4):
+            def f(x, k=k):
+                b = list(a)
+                b[k] = x
+                return oracle.obstacle_gp_factor(r, s, d["epsilon"], None, gp["delta_t"], gp["tau"], *b)[0][0]
+            np.testing.assert_allclose(H[k][0], numeric_jacobian(f, a[k], 1e-6), atol=d["tol"])
+
+
+def test_obstacle_planar_sdf_factor_arm_and_gp(oracle, golden):
+    d = golden["obstacle_planar_sdf_factor_arm"]
+    s = oracle.sdf(d["origin"], d["cell_size"], np.array(d["field"]))
+    r = oracle.robot(arm_from_golden(d))
+    rad, gp = d["spheres"][0][1], d["gp"]
+    for c in d["cases"]:
+        q = vec(c["q"])
+        err, H = oracle.obstacle_factor(r, s, d["epsilon"], q)
+        np.testing.assert_allclose(err[0], sdf_to_err(vec(c["sdf_expected"]), d["epsilon"] + rad), atol=d["tol"])
+        Hn = numeric_jacobian(lambda x: oracle.obstacle_factor(r, s, d["epsilon"], x)[0][0], q, 1e-6)
+        np.testing.assert_allclose(H[0], Hn, atol=d["tol"])
+    # GP version: q interpolates to (pi/4, 0) exactly as in the 3-D test
+    a = [np.zeros(2), np.array([math.pi * 10, 0]), np.array([math.pi, 0]), np.array([math.pi * 10, 0])]
+    err, H = oracle.obstacle_gp_factor(r, s, d["epsilon"], None, gp["delta_t"], gp["tau"], *a)
+    np.testing.assert_allclose(err[0], sdf_to_err(vec(d["cases"][1]["sdf_expected"]), d["epsilon"] + rad), atol=d["tol"])
+    for k in range(4):
+        def f(x, k=k):
+            b = list(a)
+            b[k] = x
+            return oracle.obstacle_gp_factor(r, s, d["epsilon"], None, gp["delta_t"], gp["tau"], *b)[0][0]
+        np.testing.assert_allclose(H[k][0], numeric_jacobian(f, a[k], 1e-6), atol=d["tol"])
+
+
+# ------------------------------------------------------------------ GP prior / interpolator
+def test_gp_prior_linear(oracle, golden):
+    d = golden["gp_prior_linear"]
+    for c in d["zero_error_cases"]:
+        err, _ = oracle.gp_prior_factor(3, False, d["delta_t"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(err[0], 0.0, atol=d["tol"])
+    c = d["random_case"]
+    a = [np.array(c[k], dtype=float) for k in ("p1", "v1", "p2", "v2")]
+    _, H = oracle.gp_prior_factor(3, False, d["delta_t"], *a)
+    for k in range(4):
+        def f(x, k=k):
+            b = list(a)
+            b[k] = x
+            return oracle.gp_prior_factor(3, False, d["delta_t"], *b)[0][0]
+        np.testing.assert_allclose(H[k][0], numeric_jacobian(f, a[k], 1e-6), atol=d["tol"])
+
+
+def test_gp_interpolator_linear(oracle, golden):
+    d = golden["gp_interpolator_linear"]
+    Qc = d["Qc_scale"] * np.eye(3)
+    for c in d["cases"]:
+        conf, _ = oracle.gp_interpolate(3, False, Qc, d["delta_t"], d["tau"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(conf[0], c["expect"], atol=d["tol"])
+    c = d["random_case"]
+    a = [np.array(c[k], dtype=float) for k in ("p1", "v1", "p2", "v2")]
+    H = oracle.gp_interpolate_jac(3, False, Qc, d["delta_t"], d["tau"], *a)
+    for k in range(4):
+        def f(x, k=k):
+            b = list(a)
+            b[k] = x
+            return oracle.gp_interpolate(3, False, Qc, d["delta_t"], d["tau"], *b)[0][0]
+        np.testing.assert_allclose(H[k][0], numeric_jacobian(f, a[k], 1e-6), atol=d["tol"])
+
+
+def test_lambda_psi_are_kronecker_and_independent_of_Qc(oracle):
+    """SURVEY.md a1 'derived fact': Lambda and Psi are (2x2 scalar) (x) I_D for ANY SPD Qc.  The HIP
+    kernels rely on it (8 scalars per sub-step instead of two 2Dx2D matrices)."""
+    rng = np.random.default_rng(0)
+    A = rng.normal(size=(4, 4))
+    Qc = A @ A.T + 4 * np.eye(4)
+    L, P = oracle.gp_matrices(4, Qc, 0.1, 0.03)
+    L0, P0 = oracle.gp_matrices(4, None, 0.1, 0.03)
+    np.testing.assert_allclose(L, L0, atol=1e-9)
+    np.testing.assert_allclose(P, P0, atol=1e-9)
+    for M in (L0, P0):
+        for bi in range(2):
+            for bj in range(2):
+                blk = M[bi * 4:(bi + 1) * 4, bj * 4:(bj + 1) * 4]
+                np.testing.assert_allclose(blk, blk[0, 0] * np.eye(4), atol=1e-12)
+    np.testing.assert_allclose([L0[0, 0], L0[0, 4], L0[4, 0], L0[4, 4]], [0.784, 0.0147, -12.6, 0.07], atol=1e-9)
+    np.testing.assert_allclose([P0[0, 0], P0[0, 4], P0[4, 0], P0[4, 4]], [0.216, -0.0063, 12.6, -0.33], atol=1e-9)
+
+
+# ------------------------------------------------------------------ limits (testJointLimitFactorVector.cpp)
+def test_joint_limit_factor(oracle, golden):
+    d = golden["joint_limit"]
+    for c in d["cases"]:
+        err, Hd = oracle.joint_limit_factor(d["down"], d["up"], d["thresh"], c["conf"])
+        np.testing.assert_allclose(err[0], c["err"], atol=d["tol"])
+        Hn = numeric_jacobian(lambda x: oracle.joint_limit_factor(d["down"], d["up"], d["thresh"], x)[0][0],
+                              np.array(c["conf"], dtype=float), 1e-6)
+        np.testing.assert_allclose(np.diag(Hd[0]), Hn, atol=d["tol"])

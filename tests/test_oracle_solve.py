@@ -1,0 +1,79 @@
+"""Whole-solve checks of the CPU oracle.  The reference pins NO full trajectory solve (SURVEY.md
+appendix D last row: 'parity unpinned'), so the oracle's linearize -> block-tridiagonal Cholesky
+path is cross-checked against an independent dense numpy least-squares solve of the same whitened
+Jacobian, and the optimizer loop against its own invariants."""
+import numpy as np
+import pytest
+
+from gpmp2_amd import problems
+
+
+@pytest.fixture(scope="module")
+def small_wam(oracle):
+    p = problems.wam_restarts(B=3, total_step=12, obs_check_inter=3, opt="GN", sdf="40")
+    return p, oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+
+
+def test_normal_equations_match_dense_numpy(oracle, small_wam):
+    p, r, s = small_wam
+    b = 1
+    args = (r, s, p.setting, p.start_conf[b:b + 1], p.start_vel[b:b + 1], p.end_conf[b:b + 1], p.end_vel[b:b + 1],
+            p.init[b:b + 1])
+    A, res = oracle.dense_linearize(*args)
+    Hd, Ho, g, err = oracle.linearize(*args)
+    assert err[0] == pytest.approx(0.5 * res @ res, rel=1e-12)
+    n, nb = Hd.shape[2], Hd.shape[1]
+    H = np.zeros((nb * n, nb * n))
+    for i in range(nb):
+        H[i * n:(i + 1) * n, i * n:(i + 1) * n] = Hd[0, i]
+        if i + 1 < nb:
+            H[(i + 1) * n:(i + 2) * n, i * n:(i + 1) * n] = Ho[0, i]
+            H[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n] = Ho[0, i].T
+    np.testing.assert_allclose(H, A.T @ A, rtol=1e-10, atol=1e-6 * np.abs(H).max() * 1e-6)
+    np.testing.assert_allclose(g[0].reshape(-1), A.T @ res, rtol=1e-9, atol=1e-6)
+    x, ok = oracle.block_tridiag_solve(Hd, Ho, -g)
+    assert ok[0] == 1
+    x_np = np.linalg.lstsq(A, -res, rcond=None)[0]
+    np.testing.assert_allclose(x[0].reshape(-1), x_np, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("opt", ["GN", "LM", "DOGLEG"])
+def test_optimizer_invariants(oracle, small_wam, opt):
+    p, r, s = small_wam
+    st = problems.wam_setting(12, 3, opt)
+    res = oracle.batch_optimize(r, s, st, p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
+    e0 = oracle.graph_error(r, s, st, p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
+    ef = oracle.graph_error(r, s, st, p.start_conf, p.start_vel, p.end_conf, p.end_vel, res["traj"])
+    np.testing.assert_allclose(res["error_trace"][:, 0], e0, rtol=1e-12)
+    np.testing.assert_allclose(res["final_error"], ef, rtol=1e-12)
+    assert np.all(ef < e0)                       # the no-increase guard holds
+    assert np.all(res["iters"] >= 1) and np.all(res["iters"] <= st.max_iter)
+    if opt != "GN":                              # LM / Dogleg never accept an increasing step
+        tr = res["error_trace"]
+        for b in range(p.B):
+            t = tr[b][~np.isnan(tr[b])]
+            assert np.all(np.diff(t) <= 1e-9 * t[0])
+
+
+def test_fixed_iterations_budget(oracle, small_wam):
+    p, r, s = small_wam
+    st = problems.wam_setting(12, 3, "GN")
+    st.fixed_iterations = 2
+    res = oracle.batch_optimize(r, s, st, p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
+    assert list(res["iters"]) == [2] * p.B
+
+
+def test_interpolate_arm_traj_known_answer(oracle, golden):
+    # gpmp2/planner/tests/testTrajUtils.cpp:26-54: const velocity 10, dt 0.1, 4 interpolated steps
+    Qc = 0.01 * np.eye(2)
+    for k in range(1, 5):
+        conf, vel = oracle.gp_interpolate(2, False, Qc, 0.1, 0.1 * k / 5, [0, 0], [10, 0], [1, 0], [10, 0])
+        np.testing.assert_allclose(conf[0], [0.2 * k, 0], atol=1e-6)
+        np.testing.assert_allclose(vel[0], [10, 0], atol=1e-6)
+
+
+def test_collision_cost_uses_zero_epsilon(oracle, small_wam):
+    p, r, s = small_wam
+    c = oracle.collision_cost(r, s, 12, p.init)
+    err, _ = oracle.obstacle_factor(r, s, 0.0, p.init[:, :, :7].reshape(-1, 7))
+    np.testing.assert_allclose(c, err.reshape(p.B, -1).sum(axis=1), rtol=1e-12)
