@@ -1,0 +1,889 @@
+// api.hip -- the C ABI of include/gpmp2mi.h: handle management, host-side constant
+// precomputation (GP matrices, whitening weights), marshalling and the optimizer driver loop.
+// There is deliberately no CPU compute path in this file: every entry point launches kernels.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+#include "launch.h"
+#include "plan.h"
+
+namespace g2 {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+// RAII device buffer used by the host-pointer convenience entry points
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    n = count;
+    if (count == 0) return GPMP2MI_OK;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+      p = nullptr;
+      return (e == hipErrorNoDevice) ? GPMP2MI_ERR_NO_DEVICE : GPMP2MI_ERR_ALLOC;
+    }
+    return GPMP2MI_OK;
+  }
+  int upload(const T* h, size_t count) {
+    int rc = alloc(count);
+    if (rc) return rc;
+    if (count) G2_HIP(hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice));
+    return GPMP2MI_OK;
+  }
+  int download(T* h) const {
+    if (n && h) G2_HIP(hipMemcpy(h, p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return GPMP2MI_OK;
+  }
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+};
+#define G2_TRY(expr)             \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != GPMP2MI_OK) return rc_; \
+  } while (0)
+
+static int ensure_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no usable HIP device (this library has no CPU fallback)");
+    return GPMP2MI_ERR_NO_DEVICE;
+  }
+  return GPMP2MI_OK;
+}
+
+// 2x2 scalar GP matrices (gpmp2/gp/GPutils.h:25-59 with Qc factored out)
+static void mm2(const double A[4], const double B[4], double C[4]) {
+  const double c0 = A[0] * B[0] + A[1] * B[2], c1 = A[0] * B[1] + A[1] * B[3];
+  const double c2 = A[2] * B[0] + A[3] * B[2], c3 = A[2] * B[1] + A[3] * B[3];
+  C[0] = c0; C[1] = c1; C[2] = c2; C[3] = c3;
+}
+static void gp_winv(double dt, double W[4]) {
+  W[0] = 12.0 * std::pow(dt, -3.0);
+  W[1] = W[2] = (-6.0) * std::pow(dt, -2.0);
+  W[3] = 4.0 * std::pow(dt, -1.0);
+}
+static GpCoef gp_coef(double dt, double tau) {
+  const double A[4] = {1.0 / 3 * std::pow(tau, 3.0), 1.0 / 2 * std::pow(tau, 2.0),
+                       1.0 / 2 * std::pow(tau, 2.0), tau};
+  const double CtT[4] = {1.0, 0.0, dt - tau, 1.0};  // Phi(dt - tau)^T
+  double W[4], T[4], Psi[4], PC[4];
+  gp_winv(dt, W);
+  mm2(A, CtT, T);
+  mm2(T, W, Psi);
+  const double Cdt[4] = {1.0, dt, 0.0, 1.0};
+  mm2(Psi, Cdt, PC);
+  GpCoef c;
+  c.l11 = 1.0 - PC[0];
+  c.l12 = tau - PC[1];
+  c.l21 = 0.0 - PC[2];
+  c.l22 = 1.0 - PC[3];
+  c.p11 = Psi[0];
+  c.p12 = Psi[1];
+  c.p21 = Psi[2];
+  c.p22 = Psi[3];
+  return c;
+}
+
+static bool invert_small(int n, const double* A, double* Ainv) {
+  std::vector<double> M(A, A + n * n);
+  for (int i = 0; i < n * n; i++) Ainv[i] = 0.0;
+  for (int i = 0; i < n; i++) Ainv[i * n + i] = 1.0;
+  for (int c = 0; c < n; c++) {
+    int p = c;
+    for (int i = c + 1; i < n; i++)
+      if (std::fabs(M[i * n + c]) > std::fabs(M[p * n + c])) p = i;
+    if (M[p * n + c] == 0.0) return false;
+    if (p != c)
+      for (int j = 0; j < n; j++) {
+        std::swap(M[p * n + j], M[c * n + j]);
+        std::swap(Ainv[p * n + j], Ainv[c * n + j]);
+      }
+    const double inv = 1.0 / M[c * n + c];
+    for (int j = 0; j < n; j++) {
+      M[c * n + j] *= inv;
+      Ainv[c * n + j] *= inv;
+    }
+    for (int i = 0; i < n; i++) {
+      if (i == c) continue;
+      const double f = M[i * n + c];
+      if (f == 0.0) continue;
+      for (int j = 0; j < n; j++) {
+        M[i * n + j] -= f * M[c * n + j];
+        Ainv[i * n + j] -= f * Ainv[c * n + j];
+      }
+    }
+  }
+  return true;
+}
+}  // namespace g2
+
+using namespace g2;
+
+// ============================================================================================ handles
+struct gpmp2mi_robot {
+  RobotDev h;
+  RobotDev* d = nullptr;
+};
+struct gpmp2mi_sdf {
+  SdfDev h;
+  double* plain = nullptr;
+  double* cells = nullptr;
+};
+
+struct KernelTimer {
+  bool enabled = false;
+  struct Rec {
+    const char* name;
+    hipEvent_t a, b;
+  };
+  std::vector<Rec> recs;
+  std::vector<std::string> names;
+  std::vector<double> ms;
+  std::vector<int> launches;
+  std::vector<const char*> cnames;
+  std::vector<hipEvent_t> pool;
+  size_t pool_used = 0;
+  hipEvent_t get() {
+    if (pool_used == pool.size()) {
+      hipEvent_t e;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[pool_used++];
+  }
+  void begin(const char* name, hipStream_t st) {
+    if (!enabled) return;
+    Rec r{name, get(), get()};
+    (void)hipEventRecord(r.a, st);
+    recs.push_back(r);
+  }
+  void end(hipStream_t st) {
+    if (!enabled) return;
+    (void)hipEventRecord(recs.back().b, st);
+  }
+  void reset() {
+    recs.clear();
+    pool_used = 0;
+    names.clear();
+    ms.clear();
+    launches.clear();
+  }
+  void collect() {
+    names.clear();
+    ms.clear();
+    launches.clear();
+    for (auto& r : recs) {
+      float t = 0;
+      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+      size_t k = 0;
+      for (; k < names.size(); k++)
+        if (names[k] == r.name) break;
+      if (k == names.size()) {
+        names.push_back(r.name);
+        ms.push_back(0.0);
+        launches.push_back(0);
+      }
+      ms[k] += t;
+      launches[k] += 1;
+    }
+    cnames.clear();
+    for (auto& s : names) cnames.push_back(s.c_str());
+  }
+  ~KernelTimer() {
+    for (auto e : pool) (void)hipEventDestroy(e);
+  }
+};
+
+struct gpmp2mi_plan {
+  const gpmp2mi_robot* robot = nullptr;
+  const gpmp2mi_sdf* sdf = nullptr;
+  PlanParams hp;
+  PlanBuffers pb;
+  std::vector<void*> allocs;
+  int* h_nactive = nullptr;  // pinned
+  KernelTimer timer;
+  bool problem_set = false;
+  bool optimized = false;
+  size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
+};
+
+template <class T>
+static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T));
+  if (e != hipSuccess) {
+    set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+    return GPMP2MI_ERR_ALLOC;
+  }
+  (void)hipMemset(q, 0, std::max<size_t>(count, 1) * sizeof(T));
+  p->allocs.push_back(q);
+  *ptr = (T*)q;
+  return GPMP2MI_OK;
+}
+
+extern "C" {
+
+const char* gpmp2mi_last_error(void) { return g_last_error.c_str(); }
+int gpmp2mi_version(void) { return GPMP2MI_VERSION; }
+int gpmp2mi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// -------------------------------------------------------------------------------------------- robot
+int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
+  G2_CHECK(d && out, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  G2_CHECK(d->kind >= 0 && d->kind <= 3, GPMP2MI_ERR_INVALID, "unknown robot kind");
+  G2_CHECK(d->arm_dof >= 0 && d->arm_dof <= MAXJ, GPMP2MI_ERR_UNSUPPORTED, "arm dof > 8");
+  G2_CHECK(d->nr_spheres >= 0 && d->nr_spheres <= MAXS, GPMP2MI_ERR_UNSUPPORTED, "too many body spheres");
+  const int base = (d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_BASE || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? 3 : 0;
+  const int dof = (d->kind == GPMP2MI_ROBOT_POINT) ? 2 : base + d->arm_dof;
+  G2_CHECK(d->dof == dof, GPMP2MI_ERR_INVALID, "dof does not match robot kind / arm_dof");
+  if (d->kind == GPMP2MI_ROBOT_ARM || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM)
+    G2_CHECK(d->arm_dof > 0 && d->a && d->alpha && d->d, GPMP2MI_ERR_INVALID, "missing DH parameters");
+  G2_TRY(ensure_device());
+  auto r = std::make_unique<gpmp2mi_robot>();
+  RobotDev& h = r->h;
+  std::memset(&h, 0, sizeof(h));
+  h.kind = d->kind;
+  h.dof = dof;
+  h.arm_dof = d->arm_dof;
+  h.base_dof = base;
+  h.nr_links = (d->kind == GPMP2MI_ROBOT_ARM) ? d->arm_dof
+               : (d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? d->arm_dof + 1 : 1;
+  h.nr_spheres = d->nr_spheres;
+  for (int j = 0; j < d->arm_dof; j++) {
+    h.a[j] = d->a[j];
+    h.d[j] = d->d[j];
+    h.ca[j] = std::cos(d->alpha[j]);
+    h.sa[j] = std::sin(d->alpha[j]);
+    h.bias[j] = d->theta_bias ? d->theta_bias[j] : 0.0;
+  }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 4; j++) h.base[i * 4 + j] = d->base_pose[i * 4 + j];
+  // sort spheres by link (stable) so the kinematic chain visits them in order
+  std::vector<int> order(d->nr_spheres);
+  std::iota(order.begin(), order.end(), 0);
+  for (int s = 0; s < d->nr_spheres; s++)
+    G2_CHECK(d->sphere_link[s] >= 0 && d->sphere_link[s] < h.nr_links, GPMP2MI_ERR_INVALID,
+             "sphere link id out of range");
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return d->sphere_link[a] < d->sphere_link[b]; });
+  for (int s = 0; s < d->nr_spheres; s++) {
+    const int o = order[s];
+    h.sph_link[s] = d->sphere_link[o];
+    h.sph_orig[s] = o;
+    h.sph_r[s] = d->sphere_radius[o];
+    for (int i = 0; i < 3; i++) h.sph_c[3 * s + i] = d->sphere_center[3 * o + i];
+  }
+  int s = 0;
+  for (int l = 0; l <= h.nr_links; l++) {
+    while (s < d->nr_spheres && h.sph_link[s] < l) s++;
+    h.link_first[l] = s;
+  }
+  h.link_first[h.nr_links] = d->nr_spheres;
+  G2_HIP(hipMalloc((void**)&r->d, sizeof(RobotDev)));
+  G2_HIP(hipMemcpy(r->d, &h, sizeof(RobotDev), hipMemcpyHostToDevice));
+  *out = r.release();
+  return GPMP2MI_OK;
+}
+void gpmp2mi_robot_destroy(gpmp2mi_robot* r) {
+  if (!r) return;
+  if (r->d) (void)hipFree(r->d);
+  delete r;
+}
+int gpmp2mi_robot_dof(const gpmp2mi_robot* r) { return r ? r->h.dof : -1; }
+int gpmp2mi_robot_nr_links(const gpmp2mi_robot* r) { return r ? r->h.nr_links : -1; }
+int gpmp2mi_robot_nr_spheres(const gpmp2mi_robot* r) { return r ? r->h.nr_spheres : -1; }
+
+// -------------------------------------------------------------------------------------------- sdf
+int gpmp2mi_sdf_create(int dim, const double origin[3], double cell, int nx, int ny, int nz,
+                       const double* vox, int layout, gpmp2mi_sdf** out) {
+  G2_CHECK(out && origin && vox, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  G2_CHECK(dim == 2 || dim == 3, GPMP2MI_ERR_INVALID, "dim must be 2 or 3");
+  if (dim == 2) nz = 1;
+  G2_CHECK(nx > 0 && ny > 0 && nz > 0 && cell > 0, GPMP2MI_ERR_INVALID, "bad field size");
+  G2_TRY(ensure_device());
+  auto s = std::make_unique<gpmp2mi_sdf>();
+  const size_t n = (size_t)nx * ny * nz;
+  std::vector<double> zyx;
+  const double* src = vox;
+  if (layout == GPMP2MI_SDF_LAYOUT_GTSAM) {
+    zyx.resize(n);
+    for (int z = 0; z < nz; z++)
+      for (int y = 0; y < ny; y++)
+        for (int x = 0; x < nx; x++) zyx[((size_t)z * ny + y) * nx + x] = vox[((size_t)z * nx + x) * ny + y];
+    src = zyx.data();
+  } else {
+    G2_CHECK(layout == GPMP2MI_SDF_LAYOUT_ZYX, GPMP2MI_ERR_INVALID, "unknown voxel layout");
+  }
+  SdfDev& h = s->h;
+  h.dim = dim;
+  h.nx = nx;
+  h.ny = ny;
+  h.nz = nz;
+  h.ox = origin[0];
+  h.oy = origin[1];
+  h.oz = dim == 3 ? origin[2] : 0.0;
+  h.cell = cell;
+  h.inv_cell = 1.0 / cell;
+  // upper faces exactly as SignedDistanceField.h:105-107: origin + (n - 1.0) * cell_size
+  h.hix = h.ox + (nx - 1.0) * cell;
+  h.hiy = h.oy + (ny - 1.0) * cell;
+  h.hiz = h.oz + (nz - 1.0) * cell;
+  G2_HIP(hipMalloc((void**)&s->plain, n * sizeof(double)));
+  G2_HIP(hipMemcpy(s->plain, src, n * sizeof(double), hipMemcpyHostToDevice));
+  const int nc = dim == 3 ? 8 : 4;
+  G2_HIP(hipMalloc((void**)&s->cells, n * nc * sizeof(double)));
+  h.plain = s->plain;
+  h.cells = s->cells;
+  G2_TRY(launch_sdf_pack(h, s->cells, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  *out = s.release();
+  return GPMP2MI_OK;
+}
+void gpmp2mi_sdf_destroy(gpmp2mi_sdf* s) {
+  if (!s) return;
+  if (s->plain) (void)hipFree(s->plain);
+  if (s->cells) (void)hipFree(s->cells);
+  delete s;
+}
+
+int gpmp2mi_sdf_query(const gpmp2mi_sdf* s, int M, const double* pts, double* dist, double* grad, int* inr) {
+  G2_CHECK(s && pts && dist && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  if (M == 0) return GPMP2MI_OK;
+  DevBuf<double> dp, dd, dg;
+  DevBuf<int> di;
+  G2_TRY(dp.upload(pts, (size_t)M * s->h.dim));
+  G2_TRY(dd.alloc(M));
+  if (grad) G2_TRY(dg.alloc((size_t)M * s->h.dim));
+  if (inr) G2_TRY(di.alloc(M));
+  G2_TRY(launch_sdf_query(s->h, M, dp.p, dd.p, dg.p, di.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dd.download(dist));
+  G2_TRY(dg.download(grad));
+  G2_TRY(di.download(inr));
+  return GPMP2MI_OK;
+}
+
+// -------------------------------------------------------------------------------------------- settings
+void gpmp2mi_settings_default(gpmp2mi_settings* s, int dof) {
+  std::memset(s, 0, sizeof(*s));
+  s->dof = dof;
+  s->total_step = 10;
+  s->total_time = 1.0;
+  s->conf_prior_sigma = 0.0001;
+  s->vel_prior_sigma = 0.0001;
+  s->epsilon = 0.2;
+  s->cost_sigma = 0.1;
+  s->obs_check_inter = 5;
+  s->opt_type = GPMP2MI_OPT_DOGLEG;
+  s->final_iter_no_increase = 1;
+  s->rel_thresh = 1e-2;
+  s->max_iter = 50;
+}
+void gpmp2mi_graph_opts_default(gpmp2mi_graph_opts* o) {
+  std::memset(o, 0, sizeof(*o));
+  o->lm_lambda_initial = 100.0;
+  o->lm_lambda_factor = 10.0;
+  o->lm_lambda_upper = 1e5;
+  o->lm_lambda_lower = 0.0;
+  o->lm_min_model_fidelity = 1e-3;
+  o->dogleg_delta_initial = 0.2;
+  o->abs_error_tol = 1e-5;
+  o->error_tol = 0.0;
+}
+
+// -------------------------------------------------------------------------------------------- factor level
+int gpmp2mi_forward_kinematics(const gpmp2mi_robot* r, int M, const double* conf, double* poses, double* J) {
+  G2_CHECK(r && conf && poses && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  if (M == 0) return GPMP2MI_OK;
+  const int D = r->h.dof, L = r->h.nr_links;
+  DevBuf<double> dq, dp, dj;
+  G2_TRY(dq.upload(conf, (size_t)M * D));
+  G2_TRY(dp.alloc((size_t)M * L * 16));
+  if (J) G2_TRY(dj.alloc((size_t)M * L * 6 * D));
+  G2_TRY(launch_fk(r->h, r->d, M, dq.p, dp.p, dj.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dp.download(poses));
+  G2_TRY(dj.download(J));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_sphere_centers(const gpmp2mi_robot* r, int M, const double* conf, double* centers, double* J) {
+  G2_CHECK(r && conf && centers && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  if (M == 0) return GPMP2MI_OK;
+  const int D = r->h.dof, S = r->h.nr_spheres;
+  DevBuf<double> dq, dc, dj;
+  G2_TRY(dq.upload(conf, (size_t)M * D));
+  G2_TRY(dc.alloc((size_t)M * S * 3));
+  if (J) G2_TRY(dj.alloc((size_t)M * S * 3 * D));
+  G2_TRY(launch_sphere_centers(r->h, r->d, M, dq.p, dc.p, dj.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dc.download(centers));
+  G2_TRY(dj.download(J));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_obstacle_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, double eps, int M,
+                            const double* conf, double* err, double* H1) {
+  G2_CHECK(r && s && conf && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  if (M == 0) return GPMP2MI_OK;
+  const int D = r->h.dof, S = r->h.nr_spheres;
+  DevBuf<double> dq, de, dh;
+  G2_TRY(dq.upload(conf, (size_t)M * D));
+  G2_TRY(de.alloc((size_t)M * S));
+  if (H1) G2_TRY(dh.alloc((size_t)M * S * D));
+  G2_TRY(launch_obstacle(r->h, r->d, s->h, eps, M, dq.p, de.p, dh.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(dh.download(H1));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_obstacle_gp_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, double eps, const double* Qc,
+                               double delta_t, double tau, int M, const double* c1, const double* v1,
+                               const double* c2, const double* v2, double* err, double* H1, double* H2,
+                               double* H3, double* H4) {
+  (void)Qc;  // Lambda / Psi do not depend on Qc (pinned by tests/test_oracle_known_answers.py)
+  G2_CHECK(r && s && c1 && v1 && c2 && v2 && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(r->h.base_dof == 0, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP interpolation is not built yet");
+  const bool jac = H1 || H2 || H3 || H4;
+  G2_CHECK(!jac || (H1 && H2 && H3 && H4), GPMP2MI_ERR_INVALID, "pass all four Jacobians or none");
+  if (M == 0) return GPMP2MI_OK;
+  const int D = r->h.dof, S = r->h.nr_spheres;
+  DevBuf<double> a, b, c, d, de, h1, h2, h3, h4;
+  G2_TRY(a.upload(c1, (size_t)M * D));
+  G2_TRY(b.upload(v1, (size_t)M * D));
+  G2_TRY(c.upload(c2, (size_t)M * D));
+  G2_TRY(d.upload(v2, (size_t)M * D));
+  G2_TRY(de.alloc((size_t)M * S));
+  if (jac) {
+    G2_TRY(h1.alloc((size_t)M * S * D));
+    G2_TRY(h2.alloc((size_t)M * S * D));
+    G2_TRY(h3.alloc((size_t)M * S * D));
+    G2_TRY(h4.alloc((size_t)M * S * D));
+  }
+  const GpCoef gc = gp_coef(delta_t, tau);
+  G2_TRY(launch_obstacle_gp(r->h, r->d, s->h, eps, gc, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(h1.download(H1));
+  G2_TRY(h2.download(H2));
+  G2_TRY(h3.download(H3));
+  G2_TRY(h4.download(H4));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_gp_prior_factor(int D, int lie, double dt, int M, const double* c1, const double* v1,
+                            const double* c2, const double* v2, double* err, double* H1, double* H2,
+                            double* H3, double* H4) {
+  G2_CHECK(c1 && v1 && c2 && v2 && err && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(!lie, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP prior is not built yet");
+  const bool jac = H1 || H2 || H3 || H4;
+  G2_CHECK(!jac || (H1 && H2 && H3 && H4), GPMP2MI_ERR_INVALID, "pass all four Jacobians or none");
+  if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  DevBuf<double> a, b, c, d, de, h1, h2, h3, h4;
+  G2_TRY(a.upload(c1, (size_t)M * D));
+  G2_TRY(b.upload(v1, (size_t)M * D));
+  G2_TRY(c.upload(c2, (size_t)M * D));
+  G2_TRY(d.upload(v2, (size_t)M * D));
+  G2_TRY(de.alloc((size_t)M * 2 * D));
+  if (jac) {
+    G2_TRY(h1.alloc((size_t)M * 2 * D * D));
+    G2_TRY(h2.alloc((size_t)M * 2 * D * D));
+    G2_TRY(h3.alloc((size_t)M * 2 * D * D));
+    G2_TRY(h4.alloc((size_t)M * 2 * D * D));
+  }
+  G2_TRY(launch_gp_prior_linear(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(h1.download(H1));
+  G2_TRY(h2.download(H2));
+  G2_TRY(h3.download(H3));
+  G2_TRY(h4.download(H4));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_gp_interpolate(int D, int lie, const double* Qc, double dt, double tau, int M, const double* c1,
+                           const double* v1, const double* c2, const double* v2, double* conf, double* vel) {
+  (void)Qc;
+  G2_CHECK(c1 && v1 && c2 && v2 && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(!lie, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP interpolation is not built yet");
+  if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  DevBuf<double> a, b, c, d, oc, ov;
+  G2_TRY(a.upload(c1, (size_t)M * D));
+  G2_TRY(b.upload(v1, (size_t)M * D));
+  G2_TRY(c.upload(c2, (size_t)M * D));
+  G2_TRY(d.upload(v2, (size_t)M * D));
+  if (conf) G2_TRY(oc.alloc((size_t)M * D));
+  if (vel) G2_TRY(ov.alloc((size_t)M * D));
+  G2_TRY(launch_gp_interp_linear(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(oc.download(conf));
+  G2_TRY(ov.download(vel));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_joint_limit_factor(int D, const double* down, const double* up, const double* th, int M,
+                               const double* x, double* err, double* Hd) {
+  G2_CHECK(down && up && th && x && err && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");
+  if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  DevBuf<double> a, b, c, dx, de, dh;
+  G2_TRY(a.upload(down, D));
+  G2_TRY(b.upload(up, D));
+  G2_TRY(c.upload(th, D));
+  G2_TRY(dx.upload(x, (size_t)M * D));
+  G2_TRY(de.alloc((size_t)M * D));
+  if (Hd) G2_TRY(dh.alloc((size_t)M * D));
+  G2_TRY(launch_joint_limit(D, a.p, b.p, c.p, M, dx.p, de.p, dh.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(dh.download(Hd));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_block_tridiag_solve(int B, int nblk, int n, const double* Hd, const double* Ho, const double* b,
+                                double* x, int* ok) {
+  G2_CHECK(Hd && b && x && B >= 0 && nblk > 0 && n > 0, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(nblk == 1 || Ho, GPMP2MI_ERR_INVALID, "null argument");
+  if (B == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  DevBuf<double> dd, dob, db, dx, ds;
+  DevBuf<int> dk;
+  G2_TRY(dd.upload(Hd, (size_t)B * nblk * n * n));
+  G2_TRY(dob.upload(Ho, (size_t)B * (nblk - 1) * n * n));
+  G2_TRY(db.upload(b, (size_t)B * nblk * n));
+  G2_TRY(dx.alloc((size_t)B * nblk * n));
+  G2_TRY(ds.alloc((size_t)B * nblk * 512));
+  G2_TRY(dk.alloc(B));
+  G2_TRY(launch_block_tridiag_solve(B, nblk, n, dd.p, dob.p, db.p, dx.p, dk.p, ds.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dx.download(x));
+  G2_TRY(dk.download(ok));
+  return GPMP2MI_OK;
+}
+
+// -------------------------------------------------------------------------------------------- plan
+int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, const gpmp2mi_settings* s,
+                        const gpmp2mi_graph_opts* o_in, int B, gpmp2mi_plan** out) {
+  G2_CHECK(robot && sdf && s && out, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  gpmp2mi_graph_opts o;
+  if (o_in) o = *o_in;
+  else gpmp2mi_graph_opts_default(&o);
+  const int D = robot->h.dof;
+  G2_CHECK(B > 0, GPMP2MI_ERR_INVALID, "batch size must be positive");
+  G2_CHECK(s->dof == D, GPMP2MI_ERR_INVALID, "[TrajOptimizerSetting] dof does not match the robot");
+  G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
+  G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
+  G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
+  G2_CHECK(robot->h.base_dof == 0, GPMP2MI_ERR_UNSUPPORTED, "Pose2 (Lie) planners are not built yet");
+  G2_CHECK(s->opt_type == GPMP2MI_OPT_GAUSS_NEWTON, GPMP2MI_ERR_UNSUPPORTED,
+           "only GaussNewton is built on device so far");
+  G2_CHECK(s->cost_sigma > 0 && s->conf_prior_sigma > 0 && s->vel_prior_sigma > 0, GPMP2MI_ERR_INVALID,
+           "sigmas must be positive");
+  if (s->flag_vel_limit && s->vel_limits)
+    for (int k = 0; k < D; k++)
+      G2_CHECK(s->vel_limits[k] > 0, GPMP2MI_ERR_INVALID, "[VelocityLimitFactorVector] velocity limit <= 0");
+  G2_TRY(ensure_device());
+
+  auto p = std::make_unique<gpmp2mi_plan>();
+  p->robot = robot;
+  p->sdf = sdf;
+  PlanParams& P = p->hp;
+  std::memset(&P, 0, sizeof(P));
+  P.B = B;
+  P.N = s->total_step;
+  P.I = s->obs_check_inter;
+  P.P = 1 + P.N * (P.I + 1);
+  P.Ppad = (P.P + 63) / 64 * 64;
+  P.D = D;
+  P.n = 2 * D;
+  P.NG = D * (D + 1) / 2;
+  P.REC = P.NG + D + 1;
+  P.Npad = (P.N + 1 + 63) / 64 * 64;
+  P.obs_skip_first = o.obs_skip_first_state;
+  P.flag_pos_limit = s->flag_pos_limit;
+  P.flag_vel_limit = s->flag_vel_limit;
+  P.opt_type = s->opt_type;
+  P.max_iter = s->max_iter;
+  P.no_increase = s->final_iter_no_increase;
+  P.fixed_iters = o.fixed_iterations;
+  P.lie = 0;
+  P.eps = s->epsilon;
+  P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
+  // planner/BatchTrajOptimizer-inl.h:30-31
+  P.delta_t = s->total_time / static_cast<double>(s->total_step);
+  const double inter_dt = P.delta_t / static_cast<double>(s->obs_check_inter + 1);
+  P.conf_prior_w = 1.0 / (s->conf_prior_sigma * s->conf_prior_sigma);
+  P.vel_prior_w = 1.0 / (s->vel_prior_sigma * s->vel_prior_sigma);
+  P.vdyn_w = o.vehicle_dynamics_sigma > 0 ? 1.0 / (o.vehicle_dynamics_sigma * o.vehicle_dynamics_sigma) : 0.0;
+  P.rel_thresh = s->rel_thresh;
+  P.abs_tol = o.abs_error_tol;
+  P.err_tol = o.error_tol;
+  P.lm_lambda0 = o.lm_lambda_initial;
+  P.lm_factor = o.lm_lambda_factor;
+  P.lm_upper = o.lm_lambda_upper;
+  P.lm_lower = o.lm_lambda_lower;
+  P.lm_min_fidelity = o.lm_min_model_fidelity;
+  P.dl_delta0 = o.dogleg_delta_initial;
+  for (int j = 0; j < P.I; j++) P.coef[j] = gp_coef(P.delta_t, inter_dt * static_cast<double>(j + 1));
+  gp_winv(P.delta_t, P.Winv);
+  std::vector<double> Qc(D * D, 0.0), Qi(D * D, 0.0);
+  for (int i = 0; i < D; i++) Qc[i * D + i] = 1.0;
+  if (s->Qc) std::copy(s->Qc, s->Qc + D * D, Qc.begin());
+  G2_CHECK(invert_small(D, Qc.data(), Qi.data()), GPMP2MI_ERR_INVALID, "Qc is singular");
+  std::copy(Qi.begin(), Qi.end(), P.Qc_inv);
+  for (int k = 0; k < D; k++) {
+    P.pos_lo[k] = s->joint_pos_limits_down ? s->joint_pos_limits_down[k] : -1e6;
+    P.pos_hi[k] = s->joint_pos_limits_up ? s->joint_pos_limits_up[k] : 1e6;
+    P.pos_th[k] = s->pos_limit_thresh ? s->pos_limit_thresh[k] : 1e-3;
+    const double ps = s->pos_limit_sigmas ? s->pos_limit_sigmas[k] : 1e-3;
+    P.pos_w[k] = 1.0 / (ps * ps);
+    P.vel_lim[k] = s->vel_limits ? s->vel_limits[k] : 1e6;
+    P.vel_th[k] = s->vel_limit_thresh ? s->vel_limit_thresh[k] : 1e-3;
+    const double vs = s->vel_limit_sigmas ? s->vel_limit_sigmas[k] : 1e-3;
+    P.vel_w[k] = 1.0 / (vs * vs);
+  }
+  // GP prior Hessian blocks: W = B(dt) (x) Qc^-1, Phi = [[I, dt I],[0, I]]
+  {
+    const int n = P.n;
+    const double dt = P.delta_t;
+    auto W = [&](int r, int c) { return P.Winv[(r / D) * 2 + (c / D)] * Qi[(r % D) * D + (c % D)]; };
+    // (Phi^T W)[r][c] = W[r][c] for x rows; for v rows: dt * W[x row][c] + W[v row][c]
+    auto PtW = [&](int r, int c) { return r < D ? W(r, c) : dt * W(r - D, c) + W(r, c); };
+    for (int r = 0; r < n; r++)
+      for (int c = 0; c < n; c++) {
+        P.KB[r * n + c] = W(r, c);
+        P.KO[r * n + c] = -PtW(r, c);
+        // (Phi^T W Phi)[r][c] = PtW[r][c] for x cols; v cols: dt * PtW[r][x col] + PtW[r][c]
+        P.KA[r * n + c] = c < D ? PtW(r, c) : dt * PtW(r, c - D) + PtW(r, c);
+      }
+  }
+
+  PlanBuffers& pb = p->pb;
+  std::memset(&pb, 0, sizeof(pb));
+  const size_t tsz = p->tsz();
+  G2_TRY(plan_alloc(p.get(), &pb.params, 1));
+  G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
+  G2_TRY(plan_alloc(p.get(), &pb.start_conf, (size_t)B * D));
+  G2_TRY(plan_alloc(p.get(), &pb.start_vel, (size_t)B * D));
+  G2_TRY(plan_alloc(p.get(), &pb.end_conf, (size_t)B * D));
+  G2_TRY(plan_alloc(p.get(), &pb.end_vel, (size_t)B * D));
+  G2_TRY(plan_alloc(p.get(), &pb.cur, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.last, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.trial, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.result, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.delta, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.dx_u, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.REC * P.Ppad));
+  G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * (P.n + 1) * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * (P.n + 1) * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 512));
+  G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));
+  G2_TRY(plan_alloc(p.get(), &pb.prev_err, B));
+  G2_TRY(plan_alloc(p.get(), &pb.last_err, B));
+  G2_TRY(plan_alloc(p.get(), &pb.final_err, B));
+  G2_TRY(plan_alloc(p.get(), &pb.lambda, B));
+  G2_TRY(plan_alloc(p.get(), &pb.trace, (size_t)B * (P.max_iter + 1)));
+  G2_TRY(plan_alloc(p.get(), &pb.iters, B));
+  G2_TRY(plan_alloc(p.get(), &pb.status, B));
+  G2_TRY(plan_alloc(p.get(), &pb.active, B));
+  G2_TRY(plan_alloc(p.get(), &pb.phase, B));
+  G2_TRY(plan_alloc(p.get(), &pb.n_active, 1));
+  G2_HIP(hipHostMalloc((void**)&p->h_nactive, sizeof(int), hipHostMallocDefault));
+  *out = p.release();
+  return GPMP2MI_OK;
+}
+
+void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
+  if (!p) return;
+  for (void* q : p->allocs) (void)hipFree(q);
+  if (p->h_nactive) (void)hipHostFree(p->h_nactive);
+  delete p;
+}
+
+static int plan_set_problem(gpmp2mi_plan* p, const double* sc, const double* sv, const double* ec,
+                            const double* ev, const double* init, hipMemcpyKind kind, hipStream_t st) {
+  G2_CHECK(p && sc && sv && ec && ev && init, GPMP2MI_ERR_INVALID, "null argument");
+  const size_t bd = (size_t)p->hp.B * p->hp.D * sizeof(double);
+  G2_HIP(hipMemcpyAsync(p->pb.start_conf, sc, bd, kind, st));
+  G2_HIP(hipMemcpyAsync(p->pb.start_vel, sv, bd, kind, st));
+  G2_HIP(hipMemcpyAsync(p->pb.end_conf, ec, bd, kind, st));
+  G2_HIP(hipMemcpyAsync(p->pb.end_vel, ev, bd, kind, st));
+  // `trial` doubles as the pristine copy of the initial values so optimize() can be re-run
+  G2_HIP(hipMemcpyAsync(p->pb.trial, init, p->tsz() * sizeof(double), kind, st));
+  if (kind == hipMemcpyHostToDevice) G2_HIP(hipStreamSynchronize(st));
+  p->problem_set = true;
+  p->optimized = false;
+  return GPMP2MI_OK;
+}
+int gpmp2mi_plan_set_problem(gpmp2mi_plan* p, const double* sc, const double* sv, const double* ec,
+                             const double* ev, const double* init) {
+  return plan_set_problem(p, sc, sv, ec, ev, init, hipMemcpyHostToDevice, nullptr);
+}
+int gpmp2mi_plan_set_problem_dev(gpmp2mi_plan* p, const double* sc, const double* sv, const double* ec,
+                                 const double* ev, const double* init, void* stream) {
+  return plan_set_problem(p, sc, sv, ec, ev, init, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+
+int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
+  G2_CHECK(p, GPMP2MI_ERR_INVALID, "null plan");
+  G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
+  hipStream_t st = (hipStream_t)stream;
+  const PlanParams& P = p->hp;
+  PlanBuffers& pb = p->pb;
+  p->timer.reset();
+  G2_HIP(hipMemcpyAsync(pb.cur, pb.trial, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
+  G2_TRY(launch_plan_reset(P, pb, st));
+  const int max_pass = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 1;
+  for (int pass = 0; pass < max_pass; pass++) {
+    G2_HIP(hipMemsetAsync(pb.n_active, 0, sizeof(int), st));
+    p->timer.begin("linearize", st);
+    G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
+    p->timer.end(st);
+    p->timer.begin("gn_step", st);
+    G2_TRY(launch_gn_step(P, pb, pass, st));
+    p->timer.end(st);
+    G2_HIP(hipMemcpyAsync(p->h_nactive, pb.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    G2_HIP(hipStreamSynchronize(st));
+    if (*p->h_nactive == 0) break;
+  }
+  G2_HIP(hipStreamSynchronize(st));
+  if (p->timer.enabled) p->timer.collect();
+  p->optimized = true;
+  return GPMP2MI_OK;
+}
+
+static int plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status,
+                           double* trace, hipMemcpyKind kind, hipStream_t st) {
+  G2_CHECK(p && p->optimized, GPMP2MI_ERR_INVALID, "plan has not been optimized");
+  const int B = p->hp.B;
+  if (traj) G2_HIP(hipMemcpyAsync(traj, p->pb.result, p->tsz() * sizeof(double), kind, st));
+  if (iters) G2_HIP(hipMemcpyAsync(iters, p->pb.iters, B * sizeof(int), kind, st));
+  if (ferr) G2_HIP(hipMemcpyAsync(ferr, p->pb.final_err, B * sizeof(double), kind, st));
+  if (status) G2_HIP(hipMemcpyAsync(status, p->pb.status, B * sizeof(int), kind, st));
+  if (trace)
+    G2_HIP(hipMemcpyAsync(trace, p->pb.trace, (size_t)B * (p->hp.max_iter + 1) * sizeof(double), kind, st));
+  if (kind == hipMemcpyDeviceToHost) G2_HIP(hipStreamSynchronize(st));
+  return GPMP2MI_OK;
+}
+int gpmp2mi_plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status, double* trace) {
+  return plan_get_result(p, traj, iters, ferr, status, trace, hipMemcpyDeviceToHost, nullptr);
+}
+int gpmp2mi_plan_get_result_dev(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status, void* stream) {
+  return plan_get_result(p, traj, iters, ferr, status, nullptr, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+}
+const double* gpmp2mi_plan_traj_dev(const gpmp2mi_plan* p) { return p ? p->pb.result : nullptr; }
+
+int gpmp2mi_plan_graph_error(gpmp2mi_plan* p, const double* traj, double* err) {
+  G2_CHECK(p && traj && err, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
+  DevBuf<double> dt, de;
+  G2_TRY(dt.upload(traj, p->tsz()));
+  G2_TRY(de.alloc(p->hp.B));
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, p->hp, p->pb, dt.p, p->pb.rec2, p->pb.gpu2, nullptr, nullptr));
+  G2_TRY(launch_error_reduce(p->hp, p->pb, dt.p, p->pb.rec2, p->pb.gpu2, de.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_linearize(gpmp2mi_plan* p, const double* traj, double* Hdiag, double* Hoff, double* g, double* err) {
+  G2_CHECK(p && traj, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
+  const PlanParams& P = p->hp;
+  const size_t nb = (size_t)P.B * (P.N + 1), n = P.n;
+  DevBuf<double> dt, dd, dob, dg, de;
+  G2_TRY(dt.upload(traj, p->tsz()));
+  if (Hdiag) G2_TRY(dd.alloc(nb * n * n));
+  if (Hoff) G2_TRY(dob.alloc((size_t)P.B * P.N * n * n));
+  if (g) G2_TRY(dg.alloc(nb * n));
+  if (err) G2_TRY(de.alloc(P.B));
+  // use the first record buffer's twin so an optimize() in flight is not disturbed
+  PlanBuffers pb = p->pb;
+  pb.rec = p->pb.rec2;
+  pb.gpu = p->pb.gpu2;
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, dt.p, pb.rec, pb.gpu, nullptr, nullptr));
+  G2_TRY(launch_export_normal_eq(P, pb, dt.p, dd.p, dob.p, dg.p, nullptr));
+  if (err) G2_TRY(launch_error_reduce(P, pb, dt.p, pb.rec, pb.gpu, de.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dd.download(Hdiag));
+  G2_TRY(dob.download(Hoff));
+  G2_TRY(dg.download(g));
+  G2_TRY(de.download(err));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_batch_optimize(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, const gpmp2mi_settings* s,
+                           const gpmp2mi_graph_opts* o, int B, const double* sc, const double* sv,
+                           const double* ec, const double* ev, const double* init, double* traj_out,
+                           int* iters, double* ferr, int* status) {
+  gpmp2mi_plan* p = nullptr;
+  int rc = gpmp2mi_plan_create(robot, sdf, s, o, B, &p);
+  if (rc) return rc;
+  rc = gpmp2mi_plan_set_problem(p, sc, sv, ec, ev, init);
+  if (!rc) rc = gpmp2mi_plan_optimize(p, nullptr);
+  if (!rc) rc = gpmp2mi_plan_get_result(p, traj_out, iters, ferr, status, nullptr);
+  gpmp2mi_plan_destroy(p);
+  return rc;
+}
+
+int gpmp2mi_collision_cost(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, int total_step, int B,
+                           const double* traj, double* cost) {
+  // internal::CollisionCost planner/BatchTrajOptimizer-inl.h:87-100: unary obstacle error with
+  // epsilon = 0 summed over all states; evaluated on device, summed on the host.
+  G2_CHECK(r && s && traj && cost && B >= 0 && total_step >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  const int D = r->h.dof, S = r->h.nr_spheres, M = B * (total_step + 1);
+  std::vector<double> conf((size_t)M * D), err((size_t)M * S);
+  for (int m = 0; m < M; m++)
+    for (int k = 0; k < D; k++) conf[(size_t)m * D + k] = traj[(size_t)m * 2 * D + k];
+  G2_TRY(gpmp2mi_obstacle_factor(r, s, 0.0, M, conf.data(), err.data(), nullptr));
+  for (int b = 0; b < B; b++) {
+    double c = 0.0;
+    for (int i = 0; i <= total_step; i++)
+      for (int k = 0; k < S; k++) c += err[((size_t)b * (total_step + 1) + i) * S + k];
+    cost[b] = c;
+  }
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable) {
+  G2_CHECK(p, GPMP2MI_ERR_INVALID, "null plan");
+  p->timer.enabled = enable != 0;
+  return GPMP2MI_OK;
+}
+int gpmp2mi_plan_get_timing(gpmp2mi_plan* p, int* n, const char** names, double* ms, int* launches) {
+  G2_CHECK(p && n, GPMP2MI_ERR_INVALID, "null argument");
+  const int cap = *n;
+  const int have = (int)p->timer.names.size();
+  *n = have;
+  for (int i = 0; i < std::min(cap, have); i++) {
+    if (names) names[i] = p->timer.cnames[i];
+    if (ms) ms[i] = p->timer.ms[i];
+    if (launches) launches[i] = p->timer.launches[i];
+  }
+  return GPMP2MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,253 @@
+// device_math.h -- device building blocks: SDF lookup, hinge costs, DH forward kinematics with
+// geometric sphere Jacobians.  Everything is fp64; dof-dependent loops are fully unrolled on the
+// template parameters so that per-lane arrays stay in VGPRs (no runtime-indexed private arrays).
+#pragma once
+#include "common.h"
+
+namespace g2 {
+
+// ---------------------------------------------------------------------------------------------
+// Signed distance lookup.  Arithmetic follows the reference term by term
+// (gpmp2/obstacle/SignedDistanceField.h:103-167, gpmp2/obstacle/PlanarSDF.h:71-116); the only
+// difference is the memory layout: one 64-B (3-D) / 32-B (2-D) packed cell per lookup.
+// Returns false where the reference throws SDFQueryOutOfRange.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sdf3_lookup(const SdfDev& s, double px, double py, double pz,
+                                            double& dist, double& gx, double& gy, double& gz) {
+  if (px < s.ox || px > s.hix || py < s.oy || py > s.hiy || pz < s.oz || pz > s.hiz) return false;
+  const double col = (px - s.ox) / s.cell, row = (py - s.oy) / s.cell, z = (pz - s.oz) / s.cell;
+  const double lr = floor(row), lc = floor(col), lz = floor(z);
+  const double hr = lr + 1.0, hc = lc + 1.0, hz = lz + 1.0;
+  const int lri = (int)lr, lci = (int)lc, lzi = (int)lz;
+  const double2* c =
+      reinterpret_cast<const double2*>(s.cells + (((size_t)lzi * s.ny + lri) * s.nx + lci) * 8);
+  const double2 a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];  // 4 x 16-B loads of one 64-B cell
+  // [dz][dy=row][dx=col]
+  const double v000 = a0.x, v010 = a0.y, v100 = a1.x, v110 = a1.y;  // (row,col,z): vRCZ
+  const double v001 = a2.x, v011 = a2.y, v101 = a3.x, v111 = a3.y;
+  const double wr1 = row - lr, wr0 = hr - row, wc1 = col - lc, wc0 = hc - col, wz1 = z - lz,
+               wz0 = hz - z;
+  dist = wr0 * wc0 * wz0 * v000 + wr1 * wc0 * wz0 * v100 + wr0 * wc1 * wz0 * v010 +
+         wr1 * wc1 * wz0 * v110 + wr0 * wc0 * wz1 * v001 + wr1 * wc0 * wz1 * v101 +
+         wr0 * wc1 * wz1 * v011 + wr1 * wc1 * wz1 * v111;
+  const double g_row = wc0 * wz0 * (v100 - v000) + wc1 * wz0 * (v110 - v010) +
+                       wc0 * wz1 * (v101 - v001) + wc1 * wz1 * (v111 - v011);
+  const double g_col = wr0 * wz0 * (v010 - v000) + wr1 * wz0 * (v110 - v100) +
+                       wr0 * wz1 * (v011 - v001) + wr1 * wz1 * (v111 - v101);
+  const double g_z = wr0 * wc0 * (v001 - v000) + wr1 * wc0 * (v101 - v100) +
+                     wr0 * wc1 * (v011 - v010) + wr1 * wc1 * (v111 - v110);
+  gx = g_col / s.cell;
+  gy = g_row / s.cell;
+  gz = g_z / s.cell;
+  return true;
+}
+
+__device__ __forceinline__ bool sdf2_lookup(const SdfDev& s, double px, double py, double& dist,
+                                            double& gx, double& gy) {
+  if (px < s.ox || px > s.hix || py < s.oy || py > s.hiy) return false;
+  const double col = (px - s.ox) / s.cell, row = (py - s.oy) / s.cell;
+  const double lr = floor(row), lc = floor(col), hr = lr + 1.0, hc = lc + 1.0;
+  const int lri = (int)lr, lci = (int)lc;
+  const double2* c = reinterpret_cast<const double2*>(s.cells + ((size_t)lri * s.nx + lci) * 4);
+  const double2 a0 = c[0], a1 = c[1];
+  const double v00 = a0.x, v01 = a0.y, v10 = a1.x, v11 = a1.y;  // vRC
+  dist = (hr - row) * (hc - col) * v00 + (row - lr) * (hc - col) * v10 +
+         (hr - row) * (col - lc) * v01 + (row - lr) * (col - lc) * v11;
+  const double g_row = (hc - col) * (v10 - v00) + (col - lc) * (v11 - v01);
+  const double g_col = (hr - row) * (v01 - v00) + (row - lr) * (v11 - v10);
+  gx = g_col / s.cell;
+  gy = g_row / s.cell;
+  return true;
+}
+
+// hingeLossObstacleCost  gpmp2/obstacle/ObstacleCost.h:26-78.  (hx,hy,hz) = d cost / d point.
+template <int SDIM>
+__device__ __forceinline__ double hinge_obstacle(const SdfDev& s, double px, double py, double pz,
+                                                 double eps, double& hx, double& hy, double& hz) {
+  double d, gx, gy, gz = 0.0;
+  bool ok;
+  if (SDIM == 3) ok = sdf3_lookup(s, px, py, pz, d, gx, gy, gz);
+  else ok = sdf2_lookup(s, px, py, d, gx, gy);
+  hx = hy = hz = 0.0;
+  if (!ok) return 0.0;
+  if (d > eps) return 0.0;
+  hx = -gx;
+  hy = -gy;
+  hz = -gz;
+  return eps - d;
+}
+
+// hingeLossJointLimitCost  gpmp2/kinematics/JointLimitCost.h:16-31
+__device__ __forceinline__ double hinge_limit(double p, double lo, double hi, double th, double& H) {
+  if (p < lo + th) {
+    H = -1.0;
+    return lo + th - p;
+  } else if (p <= hi - th) {
+    H = 0.0;
+    return 0.0;
+  } else {
+    H = 1.0;
+    return p - hi + th;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kinematic chain state: world rotation (columns c0,c1,c2) and origin t of the current frame.
+// ---------------------------------------------------------------------------------------------
+struct Frame {
+  double c0[3], c1[3], c2[3], t[3];
+};
+
+__device__ __forceinline__ void frame_from_3x4(const double* M, Frame& F) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    F.c0[i] = M[i * 4 + 0];
+    F.c1[i] = M[i * 4 + 1];
+    F.c2[i] = M[i * 4 + 2];
+    F.t[i] = M[i * 4 + 3];
+  }
+}
+
+// F <- F * Rz(theta) * Tz(d) * Tx(a) * Rx(alpha)   (Arm::getJointTrans, kinematics/Arm.h:93-98,
+// link_trans_notheta_ kinematics/Arm.cpp:23-27)
+__device__ __forceinline__ void dh_advance(Frame& F, double theta, double a, double d, double ca,
+                                           double sa) {
+  double s, c;
+  sincos(theta, &s, &c);
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const double n0 = c * F.c0[i] + s * F.c1[i];
+    const double n1 = -s * F.c0[i] + c * F.c1[i];
+    const double z = F.c2[i];
+    F.t[i] = F.t[i] + a * n0 + d * z;
+    F.c0[i] = n0;
+    F.c1[i] = ca * n1 + sa * z;
+    F.c2[i] = -sa * n1 + ca * z;
+  }
+}
+
+// Generic visitor-style forward kinematics over a sphere model.
+//   KIND     : GPMP2MI_ROBOT_*
+//   AD       : number of DH joints (compile time; 0 for POINT / MOBILE_BASE)
+// For every sphere (sorted by link) calls  f(sorted_index, p[3], Jcol[DOF][3])  where
+// Jcol[k] = d p / d q_k (world frame; GTSAM right-perturbation for the Pose2 part) and only the
+// first `ncols` columns are non-zero.  Equivalent to RobotModel::sphereCenters
+// (kinematics/RobotModel-inl.h:12-40) composed with Arm::forwardKinematics' pose Jacobians
+// (kinematics/Arm.cpp:105-115): column k = z_k x (p - o_k)  (SURVEY.md appendix A.2).
+template <int KIND, int AD>
+struct Kin {
+  static constexpr int BASE = (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_BASE ||
+                               KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? 3 : 0;
+  static constexpr int DOF = (KIND == GPMP2MI_ROBOT_POINT) ? 2 : BASE + AD;
+  static constexpr int NLINKS = (KIND == GPMP2MI_ROBOT_ARM) ? AD
+                                : (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? AD + 1 : 1;
+
+  template <class F>
+  __device__ __forceinline__ static void for_each_sphere(const RobotDev& R, const double (&q)[DOF],
+                                                         F&& f) {
+    double J[DOF][3];
+#pragma unroll
+    for (int k = 0; k < DOF; k++) J[k][0] = J[k][1] = J[k][2] = 0.0;
+
+    if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
+      // PointRobot::forwardKinematics  kinematics/PointRobot.cpp:15-49
+      J[0][0] = 1.0;
+      J[1][1] = 1.0;
+      for (int s = 0; s < R.nr_spheres; s++) {
+        double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
+        f(s, p, J, 2);
+      }
+      return;
+    } else {
+      Frame Fr;
+      double vt[3] = {0, 0, 0};  // vehicle origin (mobile robots)
+      if constexpr (BASE == 3) {
+        // computeBasePose3  kinematics/mobileBaseUtils.cpp:18-31
+        double s, c;
+        sincos(q[2], &s, &c);
+        Fr.c0[0] = c; Fr.c0[1] = s; Fr.c0[2] = 0;
+        Fr.c1[0] = -s; Fr.c1[1] = c; Fr.c1[2] = 0;
+        Fr.c2[0] = 0; Fr.c2[1] = 0; Fr.c2[2] = 1;
+        Fr.t[0] = q[0]; Fr.t[1] = q[1]; Fr.t[2] = 0;
+        vt[0] = q[0]; vt[1] = q[1];
+        const double bx[3] = {c, s, 0}, by[3] = {-s, c, 0};
+        // link 0 = vehicle base
+        for (int s0 = R.link_first[0]; s0 < R.link_first[1]; s0++) {
+          double p[3];
+#pragma unroll
+          for (int i = 0; i < 3; i++)
+            p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s0] + Fr.c1[i] * R.sph_c[3 * s0 + 1] +
+                   Fr.c2[i] * R.sph_c[3 * s0 + 2];
+#pragma unroll
+          for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
+          J[2][0] = -(p[1] - vt[1]);  // z x (p - t_veh)
+          J[2][1] = (p[0] - vt[0]);
+          J[2][2] = 0.0;
+          f(s0, p, J, 3);
+        }
+        if constexpr (AD > 0) {
+          // arm base = veh * base_T_arm  (computeBaseTransPose3, mobileBaseUtils.cpp:34-48)
+          Frame B;
+          frame_from_3x4(R.base, B);
+          Frame N;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            N.c0[i] = Fr.c0[i] * B.c0[0] + Fr.c1[i] * B.c0[1] + Fr.c2[i] * B.c0[2];
+            N.c1[i] = Fr.c0[i] * B.c1[0] + Fr.c1[i] * B.c1[1] + Fr.c2[i] * B.c1[2];
+            N.c2[i] = Fr.c0[i] * B.c2[0] + Fr.c1[i] * B.c2[1] + Fr.c2[i] * B.c2[2];
+            N.t[i] = Fr.t[i] + Fr.c0[i] * B.t[0] + Fr.c1[i] * B.t[1] + Fr.c2[i] * B.t[2];
+          }
+          Fr = N;
+#pragma unroll
+          for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
+        }
+      } else {
+        frame_from_3x4(R.base, Fr);
+      }
+      if constexpr (AD > 0) {
+        double zax[AD][3], org[AD][3];
+#pragma unroll
+        for (int j = 0; j < AD; j++) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            zax[j][i] = Fr.c2[i];
+            org[j][i] = Fr.t[i];
+          }
+          dh_advance(Fr, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
+          const int link = (BASE == 3) ? j + 1 : j;
+          for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) {
+            double p[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+              p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s] + Fr.c1[i] * R.sph_c[3 * s + 1] +
+                     Fr.c2[i] * R.sph_c[3 * s + 2];
+            if constexpr (BASE == 3) {
+              J[2][0] = -(p[1] - vt[1]);
+              J[2][1] = (p[0] - vt[0]);
+              J[2][2] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k <= j; k++) {
+              const double rx = p[0] - org[k][0], ry = p[1] - org[k][1], rz = p[2] - org[k][2];
+              J[BASE + k][0] = zax[k][1] * rz - zax[k][2] * ry;
+              J[BASE + k][1] = zax[k][2] * rx - zax[k][0] * rz;
+              J[BASE + k][2] = zax[k][0] * ry - zax[k][1] * rx;
+            }
+            f(s, p, J, BASE + j + 1);
+          }
+        }
+      }
+    }
+  }
+};
+
+// stage the robot model into LDS (every thread of the block must call this)
+__device__ __forceinline__ void stage_robot(RobotDev* dst_lds, const RobotDev* __restrict__ src) {
+  const int n = sizeof(RobotDev) / 4;
+  const int* s = reinterpret_cast<const int*>(src);
+  int* d = reinterpret_cast<int*>(dst_lds);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  __syncthreads();
+}
+
+}  // namespace g2

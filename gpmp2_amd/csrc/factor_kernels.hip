@@ -1,0 +1,388 @@
+// factor_kernels.hip -- factor-level kernels behind the evaluateError-style C ABI entry points
+// (include/gpmp2mi.h "factor-level entry points").  One lane per evaluation; these exist for
+// parity testing and for callers that embed single factors; the planner's hot loop uses the
+// fused kernels in plan_kernels.hip.
+#include "device_math.h"
+#include "dispatch.h"
+#include "launch.h"
+
+namespace g2 {
+
+// --------------------------------------------------------------------------- SDF packing
+// plain [nz][ny][nx] -> cells [nz][ny][nx][2^dim]; neighbour indices clamp at the upper faces
+// (their weights are exactly 0 there).
+__global__ void k_sdf_pack(int dim, int nx, int ny, int nz, const double* __restrict__ plain,
+                           double* __restrict__ cells) {
+  const size_t n = (size_t)nx * ny * nz;
+  const int nc = dim == 3 ? 8 : 4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % nx), y = (int)((i / nx) % ny), z = (int)(i / ((size_t)nx * ny));
+    const int x1 = min(x + 1, nx - 1), y1 = min(y + 1, ny - 1), z1 = min(z + 1, nz - 1);
+    for (int c = 0; c < nc; c++) {
+      const int xx = (c & 1) ? x1 : x, yy = (c & 2) ? y1 : y, zz = (c & 4) ? z1 : z;
+      cells[i * nc + c] = plain[((size_t)zz * ny + yy) * nx + xx];
+    }
+  }
+}
+
+int launch_sdf_pack(const SdfDev& s, double* cells, hipStream_t st) {
+  const size_t n = (size_t)s.nx * s.ny * s.nz;
+  const int grid = (int)std::min<size_t>((n + 255) / 256, 256 * 8);
+  hipLaunchKernelGGL(k_sdf_pack, dim3(grid), dim3(256), 0, st, s.dim, s.nx, s.ny, s.nz, s.plain, cells);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// --------------------------------------------------------------------------- SDF query
+__global__ void k_sdf_query(SdfDev s, int M, const double* __restrict__ pts, double* __restrict__ dist,
+                            double* __restrict__ grad, int* __restrict__ inr) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double d = 0, gx = 0, gy = 0, gz = 0;
+  bool ok;
+  if (s.dim == 3) ok = sdf3_lookup(s, pts[3 * m], pts[3 * m + 1], pts[3 * m + 2], d, gx, gy, gz);
+  else ok = sdf2_lookup(s, pts[2 * m], pts[2 * m + 1], d, gx, gy);
+  if (!ok) d = gx = gy = gz = 0.0;
+  dist[m] = d;
+  if (grad) {
+    grad[(size_t)m * s.dim + 0] = gx;
+    grad[(size_t)m * s.dim + 1] = gy;
+    if (s.dim == 3) grad[(size_t)m * 3 + 2] = gz;
+  }
+  if (inr) inr[m] = ok ? 1 : 0;
+}
+
+int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, double* grad, int* inr,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_sdf_query, dim3((M + 63) / 64), dim3(64), 0, st, s, M, pts, dist, grad, inr);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// --------------------------------------------------------------------------- sphere centres
+template <int KIND, int AD>
+__global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
+                                 double* __restrict__ centers, double* __restrict__ J) {
+  using K = Kin<KIND, AD>;
+  constexpr int D = K::DOF;
+  __shared__ RobotDev R;
+  stage_robot(&R, Rg);
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double q[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * D + k];
+  const int S = R.nr_spheres;
+  K::for_each_sphere(R, q, [&](int s, const double (&p)[3], const double (&Jc)[D][3], int) {
+    const int so = R.sph_orig[s];
+#pragma unroll
+    for (int i = 0; i < 3; i++) centers[((size_t)m * S + so) * 3 + i] = p[i];
+    if (J)
+#pragma unroll
+      for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < D; k++) J[(((size_t)m * S + so) * 3 + i) * D + k] = Jc[k][i];
+  });
+}
+
+// --------------------------------------------------------------------------- link poses + body Jacobians
+// ForwardKinematics::forwardKinematics(jp, none, jpx, none, J_jpx_jp): poses [L][16], J [L][6][D]
+// in GTSAM Pose3 tangent order [omega; v] (body frame)  kinematics/Arm.cpp:105-115.
+template <int KIND, int AD>
+__global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
+                     double* __restrict__ poses, double* __restrict__ Jp) {
+  using K = Kin<KIND, AD>;
+  constexpr int D = K::DOF, L = K::NLINKS, BASE = K::BASE;
+  __shared__ RobotDev R;
+  stage_robot(&R, Rg);
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double q[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * D + k];
+  double* P = poses + (size_t)m * L * 16;
+  double* Jm = Jp ? Jp + (size_t)m * L * 6 * D : nullptr;
+  auto put_pose = [&](int l, const Frame& F) {
+    double* T = P + l * 16;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      T[i * 4 + 0] = F.c0[i];
+      T[i * 4 + 1] = F.c1[i];
+      T[i * 4 + 2] = F.c2[i];
+      T[i * 4 + 3] = F.t[i];
+    }
+    T[12] = T[13] = T[14] = 0.0;
+    T[15] = 1.0;
+  };
+  // body twist of link frame F for a world-frame rotation axis w through point o (or a pure
+  // translation along w when `trans`)
+  auto put_col = [&](int l, int k, const Frame& F, const double* w, const double* o, bool trans) {
+    if (!Jm) return;
+    double om[3] = {0, 0, 0}, v[3];
+    if (trans) {
+      v[0] = w[0]; v[1] = w[1]; v[2] = w[2];
+    } else {
+      om[0] = w[0]; om[1] = w[1]; om[2] = w[2];
+      const double rx = F.t[0] - o[0], ry = F.t[1] - o[1], rz = F.t[2] - o[2];
+      v[0] = w[1] * rz - w[2] * ry;
+      v[1] = w[2] * rx - w[0] * rz;
+      v[2] = w[0] * ry - w[1] * rx;
+    }
+    double* Jl = Jm + (size_t)l * 6 * D;
+    Jl[0 * D + k] = F.c0[0] * om[0] + F.c0[1] * om[1] + F.c0[2] * om[2];
+    Jl[1 * D + k] = F.c1[0] * om[0] + F.c1[1] * om[1] + F.c1[2] * om[2];
+    Jl[2 * D + k] = F.c2[0] * om[0] + F.c2[1] * om[1] + F.c2[2] * om[2];
+    Jl[3 * D + k] = F.c0[0] * v[0] + F.c0[1] * v[1] + F.c0[2] * v[2];
+    Jl[4 * D + k] = F.c1[0] * v[0] + F.c1[1] * v[1] + F.c1[2] * v[2];
+    Jl[5 * D + k] = F.c2[0] * v[0] + F.c2[1] * v[1] + F.c2[2] * v[2];
+  };
+  if (Jm)
+    for (int i = 0; i < L * 6 * D; i++) Jm[i] = 0.0;
+
+  if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
+    Frame F;
+    F.c0[0] = 1; F.c0[1] = 0; F.c0[2] = 0; F.c1[0] = 0; F.c1[1] = 1; F.c1[2] = 0;
+    F.c2[0] = 0; F.c2[1] = 0; F.c2[2] = 1; F.t[0] = q[0]; F.t[1] = q[1]; F.t[2] = 0;
+    put_pose(0, F);
+    const double ex[3] = {1, 0, 0}, ey[3] = {0, 1, 0};
+    put_col(0, 0, F, ex, nullptr, true);
+    put_col(0, 1, F, ey, nullptr, true);
+  } else {
+    Frame F;
+    double vt[3] = {0, 0, 0}, bx[3] = {1, 0, 0}, by[3] = {0, 1, 0};
+    const double ez[3] = {0, 0, 1};
+    if constexpr (BASE == 3) {
+      double s, c;
+      sincos(q[2], &s, &c);
+      F.c0[0] = c; F.c0[1] = s; F.c0[2] = 0; F.c1[0] = -s; F.c1[1] = c; F.c1[2] = 0;
+      F.c2[0] = 0; F.c2[1] = 0; F.c2[2] = 1; F.t[0] = q[0]; F.t[1] = q[1]; F.t[2] = 0;
+      vt[0] = q[0]; vt[1] = q[1];
+      bx[0] = c; bx[1] = s; by[0] = -s; by[1] = c;
+      put_pose(0, F);
+      put_col(0, 0, F, bx, nullptr, true);
+      put_col(0, 1, F, by, nullptr, true);
+      put_col(0, 2, F, ez, vt, false);
+      if constexpr (AD > 0) {
+        Frame B, N;
+        frame_from_3x4(R.base, B);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          N.c0[i] = F.c0[i] * B.c0[0] + F.c1[i] * B.c0[1] + F.c2[i] * B.c0[2];
+          N.c1[i] = F.c0[i] * B.c1[0] + F.c1[i] * B.c1[1] + F.c2[i] * B.c1[2];
+          N.c2[i] = F.c0[i] * B.c2[0] + F.c1[i] * B.c2[1] + F.c2[i] * B.c2[2];
+          N.t[i] = F.t[i] + F.c0[i] * B.t[0] + F.c1[i] * B.t[1] + F.c2[i] * B.t[2];
+        }
+        F = N;
+      }
+    } else {
+      frame_from_3x4(R.base, F);
+    }
+    if constexpr (AD > 0) {
+      double zax[AD][3], org[AD][3];
+#pragma unroll
+      for (int j = 0; j < AD; j++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          zax[j][i] = F.c2[i];
+          org[j][i] = F.t[i];
+        }
+        dh_advance(F, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
+        const int link = (BASE == 3) ? j + 1 : j;
+        put_pose(link, F);
+        if constexpr (BASE == 3) {
+          put_col(link, 0, F, bx, nullptr, true);
+          put_col(link, 1, F, by, nullptr, true);
+          put_col(link, 2, F, ez, vt, false);
+        }
+#pragma unroll
+        for (int k = 0; k <= j; k++) put_col(link, BASE + k, F, zax[k], org[k], false);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------- obstacle factors
+// ObstacleSDFFactor / ObstaclePlanarSDFFactor ::evaluateError
+template <int KIND, int AD, int SDIM>
+__global__ void k_obstacle(const RobotDev* __restrict__ Rg, SdfDev sdf, double eps, int M,
+                           const double* __restrict__ conf, double* __restrict__ err,
+                           double* __restrict__ H1) {
+  using K = Kin<KIND, AD>;
+  constexpr int D = K::DOF;
+  __shared__ RobotDev R;
+  stage_robot(&R, Rg);
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double q[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * D + k];
+  const int S = R.nr_spheres;
+  K::for_each_sphere(R, q, [&](int s, const double (&p)[3], const double (&Jc)[D][3], int) {
+    double hx, hy, hz;
+    const double e = hinge_obstacle<SDIM>(sdf, p[0], p[1], p[2], R.sph_r[s] + eps, hx, hy, hz);
+    const int so = R.sph_orig[s];
+    err[(size_t)m * S + so] = e;
+    if (H1)
+#pragma unroll
+      for (int k = 0; k < D; k++)
+        H1[((size_t)m * S + so) * D + k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
+  });
+}
+
+// ObstacleSDFFactorGP / ObstaclePlanarSDFFactorGP ::evaluateError with
+// GaussianProcessInterpolatorLinear (vector-space robots): conf = l11 c1 + l12 v1 + p11 c2 + p12 v2
+// and H_k = Jerr_conf * (scalar_k I)   (gp/GaussianProcessInterpolatorLinear.h:62-96).
+template <int KIND, int AD, int SDIM>
+__global__ void k_obstacle_gp(const RobotDev* __restrict__ Rg, SdfDev sdf, double eps, GpCoef gc, int M,
+                              const double* __restrict__ c1, const double* __restrict__ v1,
+                              const double* __restrict__ c2, const double* __restrict__ v2,
+                              double* __restrict__ err, double* __restrict__ H1, double* __restrict__ H2,
+                              double* __restrict__ H3, double* __restrict__ H4) {
+  using K = Kin<KIND, AD>;
+  constexpr int D = K::DOF;
+  __shared__ RobotDev R;
+  stage_robot(&R, Rg);
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double q[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) {
+    const size_t o = (size_t)m * D + k;
+    q[k] = gc.l11 * c1[o] + gc.l12 * v1[o] + gc.p11 * c2[o] + gc.p12 * v2[o];
+  }
+  const int S = R.nr_spheres;
+  K::for_each_sphere(R, q, [&](int s, const double (&p)[3], const double (&Jc)[D][3], int) {
+    double hx, hy, hz;
+    const double e = hinge_obstacle<SDIM>(sdf, p[0], p[1], p[2], R.sph_r[s] + eps, hx, hy, hz);
+    const int so = R.sph_orig[s];
+    err[(size_t)m * S + so] = e;
+    if (H1)
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        const double j = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
+        const size_t o = ((size_t)m * S + so) * D + k;
+        H1[o] = j * gc.l11;
+        H2[o] = j * gc.l12;
+        H3[o] = j * gc.p11;
+        H4[o] = j * gc.p12;
+      }
+  });
+}
+
+// --------------------------------------------------------------------------- small vector factors
+// GaussianProcessPriorLinear::evaluateError  gp/GaussianProcessPriorLinear.h:57-83
+__global__ void k_gp_prior_linear(int D, double dt, int M, const double* __restrict__ c1,
+                                  const double* __restrict__ v1, const double* __restrict__ c2,
+                                  const double* __restrict__ v2, double* __restrict__ err,
+                                  double* __restrict__ H1, double* __restrict__ H2,
+                                  double* __restrict__ H3, double* __restrict__ H4) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  for (int k = 0; k < D; k++) {
+    const size_t o = (size_t)m * D + k;
+    err[(size_t)m * 2 * D + k] = c1[o] + dt * v1[o] - c2[o];
+    err[(size_t)m * 2 * D + D + k] = v1[o] - v2[o];
+  }
+  if (!H1) return;
+  const size_t hb = (size_t)m * 2 * D * D;
+  for (int i = 0; i < 2 * D * D; i++) H1[hb + i] = H2[hb + i] = H3[hb + i] = H4[hb + i] = 0.0;
+  for (int k = 0; k < D; k++) {
+    H1[hb + (size_t)k * D + k] = 1.0;
+    H2[hb + (size_t)k * D + k] = dt;
+    H2[hb + (size_t)(D + k) * D + k] = 1.0;
+    H3[hb + (size_t)k * D + k] = -1.0;
+    H4[hb + (size_t)(D + k) * D + k] = -1.0;
+  }
+}
+
+// GaussianProcessInterpolatorLinear::interpolatePose / interpolateVelocity
+__global__ void k_gp_interp_linear(int D, GpCoef gc, int M, const double* __restrict__ c1,
+                                   const double* __restrict__ v1, const double* __restrict__ c2,
+                                   const double* __restrict__ v2, double* __restrict__ conf,
+                                   double* __restrict__ vel) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  for (int k = 0; k < D; k++) {
+    const size_t o = (size_t)m * D + k;
+    if (conf) conf[o] = gc.l11 * c1[o] + gc.l12 * v1[o] + gc.p11 * c2[o] + gc.p12 * v2[o];
+    if (vel) vel[o] = gc.l21 * c1[o] + gc.l22 * v1[o] + gc.p21 * c2[o] + gc.p22 * v2[o];
+  }
+}
+
+// JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
+__global__ void k_joint_limit(int D, const double* __restrict__ down, const double* __restrict__ up,
+                              const double* __restrict__ th, int M, const double* __restrict__ x,
+                              double* __restrict__ err, double* __restrict__ Hd) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  for (int k = 0; k < D; k++) {
+    double H;
+    err[(size_t)m * D + k] = hinge_limit(x[(size_t)m * D + k], down[k], up[k], th[k], H);
+    if (Hd) Hd[(size_t)m * D + k] = H;
+  }
+}
+
+// --------------------------------------------------------------------------- launchers
+#define G2_GRID(M) dim3(((M) + 63) / 64), dim3(64), 0, st
+
+int launch_sphere_centers(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* c,
+                          double* J, hipStream_t st) {
+  G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_sphere_centers<KIND_, AD_><<<G2_GRID(M)>>>(R, M, conf, c, J)));
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* poses, double* J,
+              hipStream_t st) {
+  G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_fk<KIND_, AD_><<<G2_GRID(M)>>>(R, M, conf, poses, J)));
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_obstacle(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, int M,
+                    const double* conf, double* err, double* H1, hipStream_t st) {
+  if (s.dim == 3) {
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle<KIND_, AD_, 3><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
+  } else {
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle<KIND_, AD_, 2><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_obstacle_gp(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, const GpCoef& gc,
+                       int M, const double* c1, const double* v1, const double* c2, const double* v2,
+                       double* err, double* H1, double* H2, double* H3, double* H4, hipStream_t st) {
+  if (s.dim == 3) {
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle_gp<KIND_, AD_, 3><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
+  } else {
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle_gp<KIND_, AD_, 2><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_gp_prior_linear(int D, double dt, int M, const double* c1, const double* v1, const double* c2,
+                           const double* v2, double* err, double* H1, double* H2, double* H3, double* H4,
+                           hipStream_t st) {
+  k_gp_prior_linear<<<G2_GRID(M)>>>(D, dt, M, c1, v1, c2, v2, err, H1, H2, H3, H4);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_gp_interp_linear(int D, const GpCoef& gc, int M, const double* c1, const double* v1,
+                            const double* c2, const double* v2, double* conf, double* vel, hipStream_t st) {
+  k_gp_interp_linear<<<G2_GRID(M)>>>(D, gc, M, c1, v1, c2, v2, conf, vel);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_joint_limit(int D, const double* down, const double* up, const double* th, int M,
+                       const double* x, double* err, double* Hd, hipStream_t st) {
+  k_joint_limit<<<G2_GRID(M)>>>(D, down, up, th, M, x, err, Hd);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+}  // namespace g2

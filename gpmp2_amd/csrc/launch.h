@@ -1,0 +1,28 @@
+// launch.h -- host-callable launchers implemented in the .hip translation units.
+#pragma once
+#include "common.h"
+
+namespace g2 {
+
+// factor_kernels.hip
+int launch_sdf_pack(const SdfDev& s, double* cells, hipStream_t st);
+int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, double* grad, int* inr,
+                     hipStream_t st);
+int launch_sphere_centers(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* c,
+                          double* J, hipStream_t st);
+int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* poses, double* J,
+              hipStream_t st);
+int launch_obstacle(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, int M,
+                    const double* conf, double* err, double* H1, hipStream_t st);
+int launch_obstacle_gp(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, const GpCoef& gc,
+                       int M, const double* c1, const double* v1, const double* c2, const double* v2,
+                       double* err, double* H1, double* H2, double* H3, double* H4, hipStream_t st);
+int launch_gp_prior_linear(int D, double dt, int M, const double* c1, const double* v1, const double* c2,
+                           const double* v2, double* err, double* H1, double* H2, double* H3, double* H4,
+                           hipStream_t st);
+int launch_gp_interp_linear(int D, const GpCoef& gc, int M, const double* c1, const double* v1,
+                            const double* c2, const double* v2, double* conf, double* vel, hipStream_t st);
+int launch_joint_limit(int D, const double* down, const double* up, const double* th, int M,
+                       const double* x, double* err, double* Hd, hipStream_t st);
+
+}  // namespace g2

@@ -1,0 +1,75 @@
+// plan.h -- device-resident state of a batch of trajectory problems (gpmp2mi_plan) and the
+// launchers of the fused hot-path kernels in plan_kernels.hip.
+#pragma once
+#include "common.h"
+
+namespace g2 {
+
+constexpr int MAXI = 16;   // max obs_check_inter
+constexpr int TILE = 16;   // block-tridiagonal tile edge (n = 2*dof <= 16 in the MFMA solver)
+
+// Uniform parameters of a plan; lives in HBM, read through scalar loads.
+struct PlanParams {
+  int B, N, I, P, Ppad, D, n, NG, REC, Npad;
+  int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
+      lie;
+  double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
+  double conf_prior_w, vel_prior_w;    // 1 / sigma^2
+  double vdyn_w;                       // 1 / dynamics_sigma^2 or 0
+  double rel_thresh, abs_tol, err_tol;
+  double lm_lambda0, lm_factor, lm_upper, lm_lower, lm_min_fidelity, dl_delta0;
+  GpCoef coef[MAXI];
+  double Winv[4];                      // B(delta_t): 12/dt^3, -6/dt^2, -6/dt^2, 4/dt
+  double Qc_inv[MAXD * MAXD];
+  double pos_lo[MAXD], pos_hi[MAXD], pos_th[MAXD], pos_w[MAXD];
+  double vel_lim[MAXD], vel_th[MAXD], vel_w[MAXD];
+  // GP prior constant Hessian blocks (n x n row-major, ld = n): KA = Phi^T W Phi, KB = W,
+  // KO = -Phi^T W (block (i, i+1))
+  double KA[4 * MAXD * MAXD], KB[4 * MAXD * MAXD], KO[4 * MAXD * MAXD];
+};
+
+// Per-plan device buffers.
+struct PlanBuffers {
+  PlanParams* params;      // device copy
+  double* start_conf;      // [B][D]
+  double* start_vel;
+  double* end_conf;
+  double* end_vel;
+  double* cur;             // [B][N+1][2D]  opt->values()
+  double* last;            // [B][N+1][2D]  last_values
+  double* trial;           // [B][N+1][2D]  LM / Dogleg trial point
+  double* result;          // [B][N+1][2D]
+  double* rec;             // [B][REC][Ppad] per-point G (packed upper), g, e   (buffer 0)
+  double* rec2;            // second buffer for trial linearizations (LM / Dogleg)
+  double* gpu;             // [B][n+1][Npad] GP prior W r (n) and r^T W r, per interval end state
+  double* gpu2;
+  double* fac;             // [B][N+1][2][4][64] factor tiles (V = R^-T, W|y) for back-substitution
+  double* delta;           // [B][N+1][2D]
+  double* dx_u;            // Dogleg steepest-descent point
+  // per-trajectory scalars
+  double* cur_err;         // error at `cur`
+  double* prev_err;        // currentError of gpmp2::optimize
+  double* last_err;
+  double* final_err;
+  double* lambda;          // LM lambda / Dogleg delta
+  double* trace;           // [B][max_iter+1]
+  int* iters;
+  int* status;
+  int* active;             // 1 while the trajectory is still iterating
+  int* phase;              // optimizer-specific sub-state
+  int* n_active;           // [1] device counter
+};
+
+int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
+                     const PlanParams& hp, const PlanBuffers& pb, const double* traj, double* rec,
+                     double* gpu, const int* active, hipStream_t st);
+int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_gn_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
+int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
+                        const double* rec, const double* gpu, double* err, hipStream_t st);
+int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
+                            double* Hdiag, double* Hoff, double* g, hipStream_t st);
+int launch_block_tridiag_solve(int B, int nblk, int n, const double* Hd, const double* Ho,
+                               const double* b, double* x, int* ok, double* scratch, hipStream_t st);
+
+}  // namespace g2

@@ -1,0 +1,272 @@
+"""ctypes binding of the HIP product library (gpmp2_amd/csrc/libgpmp2mi.so, C ABI of
+include/gpmp2mi.h).  There is no Python/CPU compute path here: if the shared library is missing
+or no GPU is usable every call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _capi
+from ._capi import dptr, f64, iptr
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgpmp2mi.so")
+
+ERR_NAMES = {1: "invalid argument", 2: "no usable GPU", 3: "HIP error", 4: "unsupported", 5: "allocation failed"}
+
+
+class Gpmp2miError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gpmp2mi error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
+        self.code = code
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no fallback implementation)")
+    lib = C.CDLL(path)
+    lib.gpmp2mi_last_error.restype = C.c_char_p
+    lib.gpmp2mi_plan_traj_dev.restype = C.c_void_p
+    for name in ("gpmp2mi_robot_destroy", "gpmp2mi_sdf_destroy", "gpmp2mi_plan_destroy"):
+        getattr(lib, name).argtypes = [C.c_void_p]
+        getattr(lib, name).restype = None
+    return lib
+
+
+class _Handle:
+    def __init__(self, ptr, destroy, keep=None):
+        self.ptr, self._destroy, self.keep = ptr, destroy, keep
+
+    def close(self):
+        if self.ptr:
+            self._destroy(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Thin object wrapper; method names mirror tests/oracle.py one-to-one."""
+
+    def __init__(self, path: str = LIB_PATH):
+        self.lib = load_library(path)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise Gpmp2miError(rc, self.lib.gpmp2mi_last_error().decode())
+
+    def device_count(self):
+        return int(self.lib.gpmp2mi_device_count())
+
+    # ---------------------------------------------------------------- handles
+    def robot(self, model):
+        desc, keep = _capi.make_robot_desc(model)
+        out = C.c_void_p()
+        self._ck(self.lib.gpmp2mi_robot_create(C.byref(desc), C.byref(out)))
+        h = _Handle(out, self.lib.gpmp2mi_robot_destroy, keep)
+        h.dof, h.S, h.L = model.dof(), model.nr_body_spheres(), model.fk_model().nr_links()
+        return h
+
+    def sdf(self, origin, cell_size, data, layout=_capi.SDF_LAYOUT_ZYX):
+        data = f64(data)
+        dim = data.ndim
+        if dim == 2:
+            ny, nx, nz = data.shape[0], data.shape[1], 1
+        else:
+            nz, ny, nx = data.shape
+        org = f64(list(origin) + [0.0] * (3 - len(origin)))
+        out = C.c_void_p()
+        self._ck(self.lib.gpmp2mi_sdf_create(C.c_int(dim), dptr(org), C.c_double(cell_size), nx, ny, nz,
+                                             dptr(data), C.c_int(layout), C.byref(out)))
+        h = _Handle(out, self.lib.gpmp2mi_sdf_destroy)
+        h.dim = dim
+        return h
+
+    # ---------------------------------------------------------------- factor level
+    def sdf_query(self, sdf, points):
+        p = f64(points).reshape(-1, sdf.dim)
+        M = p.shape[0]
+        dist, grad, inr = np.zeros(M), np.zeros((M, sdf.dim)), np.zeros(M, dtype=np.int32)
+        self._ck(self.lib.gpmp2mi_sdf_query(sdf.ptr, M, dptr(p), dptr(dist), dptr(grad), iptr(inr)))
+        return dist, grad, inr
+
+    def forward_kinematics(self, robot, conf):
+        q = f64(conf).reshape(-1, robot.dof)
+        M = q.shape[0]
+        poses, J = np.zeros((M, robot.L, 4, 4)), np.zeros((M, robot.L, 6, robot.dof))
+        self._ck(self.lib.gpmp2mi_forward_kinematics(robot.ptr, M, dptr(q), dptr(poses), dptr(J)))
+        return poses, J
+
+    def sphere_centers(self, robot, conf):
+        q = f64(conf).reshape(-1, robot.dof)
+        M = q.shape[0]
+        c, J = np.zeros((M, robot.S, 3)), np.zeros((M, robot.S, 3, robot.dof))
+        self._ck(self.lib.gpmp2mi_sphere_centers(robot.ptr, M, dptr(q), dptr(c), dptr(J)))
+        return c, J
+
+    def obstacle_factor(self, robot, sdf, epsilon, conf):
+        q = f64(conf).reshape(-1, robot.dof)
+        M = q.shape[0]
+        err, H = np.zeros((M, robot.S)), np.zeros((M, robot.S, robot.dof))
+        self._ck(self.lib.gpmp2mi_obstacle_factor(robot.ptr, sdf.ptr, C.c_double(epsilon), M, dptr(q),
+                                                  dptr(err), dptr(H)))
+        return err, H
+
+    def obstacle_gp_factor(self, robot, sdf, epsilon, Qc, delta_t, tau, c1, v1, c2, v2):
+        D = robot.dof
+        c1, v1, c2, v2 = (f64(a).reshape(-1, D) for a in (c1, v1, c2, v2))
+        M = c1.shape[0]
+        Q = None if Qc is None else f64(Qc)
+        err = np.zeros((M, robot.S))
+        H = [np.zeros((M, robot.S, D)) for _ in range(4)]
+        self._ck(self.lib.gpmp2mi_obstacle_gp_factor(robot.ptr, sdf.ptr, C.c_double(epsilon), dptr(Q),
+                                                     C.c_double(delta_t), C.c_double(tau), M, dptr(c1),
+                                                     dptr(v1), dptr(c2), dptr(v2), dptr(err),
+                                                     *[dptr(h) for h in H]))
+        return err, H
+
+    def gp_prior_factor(self, dof, lie, delta_t, c1, v1, c2, v2):
+        c1, v1, c2, v2 = (f64(a).reshape(-1, dof) for a in (c1, v1, c2, v2))
+        M = c1.shape[0]
+        err = np.zeros((M, 2 * dof))
+        H = [np.zeros((M, 2 * dof, dof)) for _ in range(4)]
+        self._ck(self.lib.gpmp2mi_gp_prior_factor(dof, int(lie), C.c_double(delta_t), M, dptr(c1), dptr(v1),
+                                                  dptr(c2), dptr(v2), dptr(err), *[dptr(h) for h in H]))
+        return err, H
+
+    def gp_interpolate(self, dof, lie, Qc, delta_t, tau, c1, v1, c2, v2):
+        c1, v1, c2, v2 = (f64(a).reshape(-1, dof) for a in (c1, v1, c2, v2))
+        M = c1.shape[0]
+        Q = None if Qc is None else f64(Qc)
+        conf, vel = np.zeros((M, dof)), np.zeros((M, dof))
+        self._ck(self.lib.gpmp2mi_gp_interpolate(dof, int(lie), dptr(Q), C.c_double(delta_t), C.c_double(tau),
+                                                 M, dptr(c1), dptr(v1), dptr(c2), dptr(v2), dptr(conf), dptr(vel)))
+        return conf, vel
+
+    def joint_limit_factor(self, down, up, thresh, x):
+        down, up, thresh = f64(down).reshape(-1), f64(up).reshape(-1), f64(thresh).reshape(-1)
+        D = down.size
+        x = f64(x).reshape(-1, D)
+        err, Hd = np.zeros_like(x), np.zeros_like(x)
+        self._ck(self.lib.gpmp2mi_joint_limit_factor(D, dptr(down), dptr(up), dptr(thresh), x.shape[0],
+                                                     dptr(x), dptr(err), dptr(Hd)))
+        return err, Hd
+
+    def block_tridiag_solve(self, Hd, Ho, b):
+        Hd, Ho, b = f64(Hd), f64(Ho), f64(b)
+        B, nblk, n = Hd.shape[0], Hd.shape[1], Hd.shape[2]
+        x, ok = np.zeros((B, nblk, n)), np.zeros(B, dtype=np.int32)
+        self._ck(self.lib.gpmp2mi_block_tridiag_solve(B, nblk, n, dptr(Hd), dptr(Ho), dptr(b), dptr(x), iptr(ok)))
+        return x, ok
+
+    def collision_cost(self, robot, sdf, total_step, traj):
+        t = f64(traj).reshape(-1, total_step + 1, 2 * robot.dof)
+        cost = np.zeros(t.shape[0])
+        self._ck(self.lib.gpmp2mi_collision_cost(robot.ptr, sdf.ptr, total_step, t.shape[0], dptr(t), dptr(cost)))
+        return cost
+
+    # ---------------------------------------------------------------- plans
+    def plan(self, robot, sdf, setting, B):
+        return Plan(self, robot, sdf, setting, B)
+
+    # graph-level helpers with the oracle's call shape
+    def _plan_for(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, traj):
+        D = setting.dof
+        sc = f64(start_conf).reshape(-1, D)
+        pl = Plan(self, robot, sdf, setting, sc.shape[0])
+        t = f64(traj).reshape(sc.shape[0], setting.total_step + 1, 2 * D)
+        pl.set_problem(start_conf, start_vel, end_conf, end_vel, t)
+        return pl, t
+
+    def graph_error(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, traj):
+        pl, t = self._plan_for(robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, traj)
+        return pl.graph_error(t)
+
+    def linearize(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, traj):
+        pl, t = self._plan_for(robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, traj)
+        return pl.linearize(t)
+
+    def batch_optimize(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, init):
+        pl, t = self._plan_for(robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, init)
+        pl.optimize()
+        return pl.result()
+
+
+class Plan:
+    """gpmp2mi_plan: B trajectory problems resident on the GPU."""
+
+    def __init__(self, eng: Engine, robot, sdf, setting, B: int):
+        self.eng, self.robot, self.sdf, self.setting, self.B = eng, robot, sdf, setting, int(B)
+        s, o, keep = _capi.make_settings(setting)
+        self._keep = (s, o, keep)
+        out = C.c_void_p()
+        eng._ck(eng.lib.gpmp2mi_plan_create(robot.ptr, sdf.ptr, C.byref(s), C.byref(o), self.B, C.byref(out)))
+        self.h = _Handle(out, eng.lib.gpmp2mi_plan_destroy)
+        self.D, self.N = setting.dof, setting.total_step
+
+    def close(self):
+        self.h.close()
+
+    def set_problem(self, start_conf, start_vel, end_conf, end_vel, init):
+        D, B = self.D, self.B
+        a = [f64(x).reshape(B, D) for x in (start_conf, start_vel, end_conf, end_vel)]
+        t = f64(init).reshape(B, self.N + 1, 2 * D)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_set_problem(self.h.ptr, *[dptr(x) for x in a], dptr(t)))
+
+    def set_problem_dev(self, start_conf, start_vel, end_conf, end_vel, init, stream=None):
+        """device pointers (ints, e.g. torch.Tensor.data_ptr()) of contiguous fp64 buffers."""
+        args = [C.c_void_p(int(x)) for x in (start_conf, start_vel, end_conf, end_vel, init)]
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_set_problem_dev(self.h.ptr, *args, C.c_void_p(stream or 0)))
+
+    def optimize(self, stream=None):
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_optimize(self.h.ptr, C.c_void_p(stream or 0)))
+
+    def result(self):
+        B, D, N = self.B, self.D, self.N
+        traj = np.zeros((B, N + 1, 2 * D))
+        iters, status = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32)
+        ferr, trace = np.zeros(B), np.zeros((B, self.setting.max_iter + 1))
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_get_result(self.h.ptr, dptr(traj), iptr(iters), dptr(ferr),
+                                                          iptr(status), dptr(trace)))
+        return dict(traj=traj, iters=iters, final_error=ferr, status=status, error_trace=trace)
+
+    def result_counts(self):
+        B = self.B
+        iters, status, ferr = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros(B)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_get_result(self.h.ptr, None, iptr(iters), dptr(ferr), iptr(status), None))
+        return iters, status, ferr
+
+    def traj_dev_ptr(self):
+        return int(self.eng.lib.gpmp2mi_plan_traj_dev(self.h.ptr))
+
+    def graph_error(self, traj):
+        t = f64(traj).reshape(self.B, self.N + 1, 2 * self.D)
+        err = np.zeros(self.B)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_graph_error(self.h.ptr, dptr(t), dptr(err)))
+        return err
+
+    def linearize(self, traj):
+        B, n, nb = self.B, 2 * self.D, self.N + 1
+        t = f64(traj).reshape(B, nb, n)
+        Hd, Ho = np.zeros((B, nb, n, n)), np.zeros((B, nb - 1, n, n))
+        g, err = np.zeros((B, nb, n)), np.zeros(B)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_linearize(self.h.ptr, dptr(t), dptr(Hd), dptr(Ho), dptr(g), dptr(err)))
+        return Hd, Ho, g, err
+
+    def enable_timing(self, on=True):
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_enable_timing(self.h.ptr, int(on)))
+
+    def timing(self):
+        n = C.c_int(16)
+        names = (C.c_char_p * 16)()
+        ms = (C.c_double * 16)()
+        launches = (C.c_int * 16)()
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_get_timing(self.h.ptr, C.byref(n), names, ms, launches))
+        return {names[i].decode(): dict(ms=ms[i], launches=launches[i]) for i in range(min(n.value, 16))}

@@ -1,0 +1,221 @@
+"""GPU parity, factor level: every C-ABI factor entry point against (a) the reference's own
+known-answer values (tests/golden) and (b) the CPU oracle on seeded random inputs.
+Tolerance: 1e-9 absolute on fp64 residuals / Jacobians (BASELINE.md parity gate); the golden
+literals keep the reference's own 1e-6 / 1e-3 / 1e-9."""
+import math
+
+import numpy as np
+import pytest
+
+import gpmp2_amd as g
+from gpmp2_amd import problems
+from helpers import arm_from_golden, num, sdf_to_err, vec
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+
+
+def test_library_reports_a_gpu(engine):
+    assert engine.device_count() >= 1
+
+
+def test_sdf3d_golden_and_oracle(engine, oracle, golden):
+    d = golden["sdf3d"]
+    data = np.array(d["slices"])
+    s, so = engine.sdf(d["origin"], d["cell_size"], data), oracle.sdf(d["origin"], d["cell_size"], data)
+    for q in d["queries"]:
+        dist, _, inr = engine.sdf_query(s, [q["point"]])
+        assert inr[0] == 1 and abs(dist[0] - q["value"]) <= q["tol"]
+    rng = np.random.default_rng(1)
+    pts = rng.uniform([-0.25, -0.25, -0.15], [0.25, 0.25, 0.15], size=(500, 3))
+    pts[:5] = [[0.2, 0.2, 0.1], [-0.2, -0.2, -0.1], [0.2, 0, 0], [0, 0.2, 0.05], [0.1, 0.1, 0.1]]  # faces
+    a, b = engine.sdf_query(s, pts), oracle.sdf_query(so, pts)
+    assert np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[0], b[0], atol=1e-9 * 4142)   # the fixture's 4142 typo cell
+    np.testing.assert_allclose(a[1], b[1], atol=1e-9 * 41420)
+
+
+def test_sdf2d_golden_and_oracle(engine, oracle, golden):
+    d = golden["sdf2d"]
+    data = np.array(d["data"])
+    s, so = engine.sdf(d["origin"], d["cell_size"], data), oracle.sdf(d["origin"], d["cell_size"], data)
+    for q in d["queries"]:
+        dist, _, _ = engine.sdf_query(s, [q["point"]])
+        assert abs(dist[0] - q["value"]) <= q["tol"]
+    pts = np.random.default_rng(2).uniform(-0.25, 0.25, size=(300, 2))
+    pts[:3] = [[0.2, 0.2], [-0.2, -0.2], [0.2, -0.1]]
+    a, b = engine.sdf_query(s, pts), oracle.sdf_query(so, pts)
+    assert np.array_equal(a[2], b[2])
+    np.testing.assert_allclose(a[0], b[0], atol=TOL)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-8)
+
+
+def test_sdf_gtsam_layout_equals_zyx(engine):
+    rng = np.random.default_rng(3)
+    data = rng.normal(size=(4, 5, 6))                      # [z][y][x]
+    gts = np.ascontiguousarray(np.transpose(data, (0, 2, 1)))  # [z][x][y] = column-major slices
+    a = engine.sdf([0, 0, 0], 0.5, data)
+    b = engine.sdf([0, 0, 0], 0.5, gts.reshape(4, 5, 6), layout=1)
+    pts = rng.uniform(0, [2.5, 2.0, 1.5], size=(100, 3))
+    np.testing.assert_array_equal(engine.sdf_query(a, pts)[0], engine.sdf_query(b, pts)[0])
+
+
+@pytest.mark.parametrize("which", ["two_link", "three_link", "wam"])
+def test_arm_fk_golden_and_oracle(engine, oracle, golden, which):
+    d = golden["arm_fk"][which]
+    if which == "two_link":
+        arm = g.Arm(2, d["a"], d["alpha"], d["d"], g.pose3(g.rot_yaw(num(d["base_yaw"])), d["base_xyz"]))
+        q0 = vec(d["cases"][1]["q"])
+    else:
+        arm = g.Arm(len(d["a"]), d["a"], vec(d["alpha"]), d["d"])
+        q0 = vec(d["q"])
+    model = g.ArmModel(arm, [])
+    r, ro = engine.robot(model), oracle.robot(model)
+    poses, _ = engine.forward_kinematics(r, q0)
+    if which == "two_link":
+        c = d["cases"][1]
+        for l in range(2):
+            np.testing.assert_allclose(poses[0, l], g.pose3(g.rot_yaw(num(c["yaw"][l])), c["xyz"][l]), atol=c["tol"])
+    else:
+        np.testing.assert_allclose(poses[0, :, :3, 3], np.array(d["xyz"]), atol=d["tol"])
+    q = np.random.default_rng(4).uniform(-3, 3, size=(64, arm.dof()))
+    (pa, ja), (pb, jb) = engine.forward_kinematics(r, q), oracle.forward_kinematics(ro, q)
+    scale = max(1.0, np.abs(pb).max())
+    np.testing.assert_allclose(pa, pb, atol=TOL * scale)
+    np.testing.assert_allclose(ja, jb, atol=TOL * scale)
+
+
+def test_sphere_centers_golden_and_oracle(engine, oracle, golden):
+    d = golden["arm_model"]
+    arm = g.Arm(2, d["a"], d["alpha"], d["d"], g.pose3(t=d["base_xyz"]))
+    model = g.ArmModel(arm, [g.BodySphere(int(s[0]), s[1], s[2:5]) for s in d["spheres"]])
+    r = engine.robot(model)
+    for c in d["cases"]:
+        ctr, _ = engine.sphere_centers(r, vec(c["q"]))
+        np.testing.assert_allclose(ctr[0], np.array(c["centers"]), atol=1e-9)
+    wam = g.generateArm("WAMArm")
+    r, ro = engine.robot(wam), oracle.robot(wam)
+    q = np.random.default_rng(5).uniform(-2.5, 2.5, size=(128, 7))
+    (ca, ja), (cb, jb) = engine.sphere_centers(r, q), oracle.sphere_centers(ro, q)
+    np.testing.assert_allclose(ca, cb, atol=TOL)
+    np.testing.assert_allclose(ja, jb, atol=TOL)
+
+
+def test_point_robot_golden_and_oracle(engine, oracle, golden):
+    d = golden["point_robot"]
+    model = g.generatePointRobot(1.5)
+    r, ro = engine.robot(model), oracle.robot(model)
+    poses, _ = engine.forward_kinematics(r, d["q"])
+    np.testing.assert_allclose(poses[0, 0], g.pose3(t=d["pose_xyz"]), atol=1e-12)
+    q = np.random.default_rng(6).uniform(-10, 10, size=(20, 2))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=TOL)
+        np.testing.assert_allclose(a[1], b[1], atol=TOL)
+
+
+def test_obstacle_factor_golden(engine, golden):
+    d = golden["obstacle_sdf_factor_arm"]
+    s = engine.sdf(d["origin"], d["cell_size"], np.array(d["slices"]))
+    r = engine.robot(arm_from_golden(d))
+    rad, gp = d["spheres"][0][1], d["gp"]
+    for c in d["unary_cases"]:
+        err, _ = engine.obstacle_factor(r, s, d["epsilon"], vec(c["q"]))
+        np.testing.assert_allclose(err[0], sdf_to_err(c["sdf_expected"], d["epsilon"] + rad), atol=d["tol"])
+    for c in d["gp_cases"]:
+        a = [vec(c[k]) for k in ("q1", "qdot1", "q2", "qdot2")]
+        err, _ = engine.obstacle_gp_factor(r, s, d["epsilon"], None, gp["delta_t"], gp["tau"], *a)
+        np.testing.assert_allclose(err[0], sdf_to_err(c["sdf_expected"], d["epsilon"] + rad), atol=d["tol"])
+
+
+def test_obstacle_planar_factor_golden(engine, golden):
+    d = golden["obstacle_planar_sdf_factor_arm"]
+    s = engine.sdf(d["origin"], d["cell_size"], np.array(d["field"]))
+    r = engine.robot(arm_from_golden(d))
+    rad = d["spheres"][0][1]
+    for c in d["cases"]:
+        err, _ = engine.obstacle_factor(r, s, d["epsilon"], vec(c["q"]))
+        np.testing.assert_allclose(err[0], sdf_to_err(vec(c["sdf_expected"]), d["epsilon"] + rad), atol=d["tol"])
+
+
+@pytest.mark.parametrize("case", ["wam3d", "arm3_2d", "point2d"])
+def test_obstacle_factors_vs_oracle(engine, oracle, case):
+    rng = np.random.default_rng(7)
+    if case == "wam3d":
+        p = problems.wam_restarts(B=1, sdf="40")
+        q = rng.uniform(-2.0, 2.0, size=(256, 7))
+        dt, tau = 0.02, 0.02 / 6 * 2
+    elif case == "arm3_2d":
+        p = problems.arm3_planner()
+        q = rng.uniform(-2.0, 2.0, size=(256, 3))
+        dt, tau = 0.1, 0.025
+    else:
+        p = problems.point_robot_2d()
+        q = rng.uniform([-19, -9], [19, 19], size=(256, 2))
+        dt, tau = 0.5, 0.2
+    D = p.model.dof()
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    eps = p.setting.epsilon
+    (ea, ha), (eb, hb) = engine.obstacle_factor(r, s, eps, q), oracle.obstacle_factor(ro, so, eps, q)
+    assert (eb > 0).sum() > 10          # the sample actually exercises the hinge
+    np.testing.assert_allclose(ea, eb, atol=TOL)
+    np.testing.assert_allclose(ha, hb, atol=1e-8)
+    v = rng.normal(size=(256, D))
+    q2 = q + dt * v + 0.01 * rng.normal(size=(256, D))
+    v2 = v + 0.1 * rng.normal(size=(256, D))
+    (ea, Ha), (eb, Hb) = (f(rr, ss, eps, None, dt, tau, q, v, q2, v2) for f, rr, ss in
+                          ((engine.obstacle_gp_factor, r, s), (oracle.obstacle_gp_factor, ro, so)))
+    np.testing.assert_allclose(ea, eb, atol=TOL)
+    for k in range(4):
+        np.testing.assert_allclose(Ha[k], Hb[k], atol=1e-8)
+
+
+def test_gp_prior_and_interpolator(engine, oracle, golden):
+    d = golden["gp_interpolator_linear"]
+    Qc = d["Qc_scale"] * np.eye(3)
+    for c in d["cases"]:
+        conf, _ = engine.gp_interpolate(3, False, Qc, d["delta_t"], d["tau"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(conf[0], c["expect"], atol=d["tol"])
+    for k in range(1, 5):   # gpmp2/planner/tests/testTrajUtils.cpp:26-54
+        conf, vel = engine.gp_interpolate(2, False, 0.01 * np.eye(2), 0.1, 0.1 * k / 5, [0, 0], [10, 0], [1, 0], [10, 0])
+        np.testing.assert_allclose(conf[0], [0.2 * k, 0], atol=1e-6)
+        np.testing.assert_allclose(vel[0], [10, 0], atol=1e-6)
+    rng = np.random.default_rng(8)
+    a = [rng.normal(size=(50, 5)) for _ in range(4)]
+    A = rng.normal(size=(5, 5))
+    Q = A @ A.T + 5 * np.eye(5)
+    for x, y in zip(engine.gp_interpolate(5, False, Q, 0.3, 0.11, *a), oracle.gp_interpolate(5, False, Q, 0.3, 0.11, *a)):
+        np.testing.assert_allclose(x, y, atol=1e-9 * 10)
+    (ea, Ha), (eb, Hb) = engine.gp_prior_factor(5, False, 0.3, *a), oracle.gp_prior_factor(5, False, 0.3, *a)
+    np.testing.assert_allclose(ea, eb, atol=TOL)
+    for k in range(4):
+        np.testing.assert_allclose(Ha[k], Hb[k], atol=TOL)
+    g0 = golden["gp_prior_linear"]
+    for c in g0["zero_error_cases"]:
+        err, _ = engine.gp_prior_factor(3, False, g0["delta_t"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(err[0], 0.0, atol=g0["tol"])
+
+
+def test_joint_limit_factor(engine, oracle, golden):
+    d = golden["joint_limit"]
+    for c in d["cases"]:
+        err, _ = engine.joint_limit_factor(d["down"], d["up"], d["thresh"], c["conf"])
+        np.testing.assert_allclose(err[0], c["err"], atol=d["tol"])
+    x = np.random.default_rng(9).uniform(-12, 12, size=(200, 2))
+    x[:4] = [[-3, -8], [3, 8], [-3 - 1e-12, 8 + 1e-12], [0, 0]]     # the strict / non-strict edges
+    a, b = engine.joint_limit_factor(d["down"], d["up"], d["thresh"], x), oracle.joint_limit_factor(d["down"], d["up"], d["thresh"], x)
+    np.testing.assert_array_equal(a[0], b[0])
+    np.testing.assert_array_equal(a[1], b[1])
+
+
+def test_empty_batches_and_bad_arguments(engine):
+    model = g.generateArm("WAMArm")
+    r = engine.robot(model)
+    c, J = engine.sphere_centers(r, np.zeros((0, 7)))
+    assert c.shape == (0, 16, 3)
+    from gpmp2_amd.engine import Gpmp2miError
+    bad = g.ArmModel(g.Arm(2, [1, 1], [0, 0], [0, 0]), [g.BodySphere(0, 0.1, (0, 0, 0))])
+    bad.spheres[0].link_id = 5
+    with pytest.raises(Gpmp2miError):
+        engine.robot(bad)

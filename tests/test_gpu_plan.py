@@ -1,0 +1,196 @@
+"""GPU parity, graph level: linearization (block-tridiagonal normal equations), the batched
+block-tridiagonal Cholesky, and the whole Gauss-Newton solve against the CPU oracle.
+
+Stated tolerances (BASELINE.md parity gate): normal-equation entries and gradients relative 1e-9
+of the block's largest entry; per-iteration graph error relative 1e-9; final trajectory absolute
+1e-6; identical per-trajectory iteration counts and status codes."""
+import numpy as np
+import pytest
+
+from gpmp2_amd import problems
+
+pytestmark = pytest.mark.gpu
+
+
+def _handles(engine, oracle, p):
+    return (engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data),
+            oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data))
+
+
+def _args(p):
+    return p.start_conf, p.start_vel, p.end_conf, p.end_vel
+
+
+@pytest.fixture(scope="module")
+def small_wam():
+    return problems.wam_restarts(B=5, total_step=12, obs_check_inter=3, opt="GN", sdf="40")
+
+
+@pytest.mark.parametrize("inter", [0, 3])
+def test_linearize_matches_oracle(engine, oracle, inter):
+    p = problems.wam_restarts(B=4, total_step=9, obs_check_inter=inter, opt="GN", sdf="40")
+    r, s, ro, so = _handles(engine, oracle, p)
+    a = engine.linearize(r, s, p.setting, *_args(p), p.init)
+    b = oracle.linearize(ro, so, p.setting, *_args(p), p.init)
+    for x, y in zip(a[:3], b[:3]):
+        scale = np.abs(y).max()
+        np.testing.assert_allclose(x, y, atol=1e-9 * scale)
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    np.testing.assert_allclose(engine.graph_error(r, s, p.setting, *_args(p), p.init), b[3], rtol=1e-9)
+
+
+def test_linearize_with_limits_and_planar_sdf(engine, oracle):
+    p = problems.arm3_planner()
+    p.setting.setGaussNewton()
+    rng = np.random.default_rng(0)
+    traj = p.init + 0.3 * rng.normal(size=p.init.shape)      # pushes some joints over the limits
+    r, s, ro, so = _handles(engine, oracle, p)
+    a = engine.linearize(r, s, p.setting, *_args(p), traj)
+    b = oracle.linearize(ro, so, p.setting, *_args(p), traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+
+
+def test_linearize_point_robot_skip_first(engine, oracle):
+    p = problems.point_robot_2d()
+    r, s, ro, so = _handles(engine, oracle, p)
+    a = engine.linearize(r, s, p.setting, *_args(p), p.init)
+    b = oracle.linearize(ro, so, p.setting, *_args(p), p.init)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+
+
+@pytest.mark.parametrize("n,nblk", [(14, 101), (4, 11), (6, 51), (1, 7), (15, 3), (10, 1)])
+def test_block_tridiag_solve(engine, oracle, n, nblk):
+    rng = np.random.default_rng(n * 100 + nblk)
+    B = 3
+    # SPD block-tridiagonal from a random banded Jacobian
+    Hd, Ho = np.zeros((B, nblk, n, n)), np.zeros((B, max(nblk - 1, 0), n, n))
+    for b in range(B):
+        for i in range(nblk):
+            A = rng.normal(size=(3 * n, 2 * n))
+            Hd[b, i] += A[:, :n].T @ A[:, :n] + 1e-3 * np.eye(n)
+            if i + 1 < nblk:
+                Hd[b, i + 1] += A[:, n:].T @ A[:, n:]
+                Ho[b, i] = A[:, n:].T @ A[:, :n]
+    rhs = rng.normal(size=(B, nblk, n))
+    x, ok = engine.block_tridiag_solve(Hd, Ho, rhs)
+    xo, oko = oracle.block_tridiag_solve(Hd, Ho, rhs)
+    assert list(ok) == [1] * B and list(oko) == [1] * B
+    # independent dense check
+    for b in range(B):
+        H = np.zeros((nblk * n, nblk * n))
+        for i in range(nblk):
+            H[i * n:(i + 1) * n, i * n:(i + 1) * n] = Hd[b, i]
+            if i + 1 < nblk:
+                H[(i + 1) * n:(i + 2) * n, i * n:(i + 1) * n] = Ho[b, i]
+                H[i * n:(i + 1) * n, (i + 1) * n:(i + 2) * n] = Ho[b, i].T
+        xd = np.linalg.solve(H, rhs[b].reshape(-1))
+        cond = np.linalg.cond(H)
+        np.testing.assert_allclose(x[b].reshape(-1), xd, atol=1e-13 * cond * np.abs(xd).max())
+    np.testing.assert_allclose(x, xo, atol=1e-9 * np.abs(xo).max())
+
+
+def test_block_tridiag_solve_flags_indefinite(engine):
+    Hd = np.tile(np.eye(4), (2, 3, 1, 1))
+    Hd[1, 1, 2, 2] = -1.0
+    x, ok = engine.block_tridiag_solve(Hd, np.zeros((2, 2, 4, 4)), np.ones((2, 3, 4)))
+    assert list(ok) == [1, 0]
+    np.testing.assert_allclose(x[0], 1.0, atol=1e-14)
+
+
+def _compare_solves(res, ref, max_iter):
+    assert list(res["iters"]) == list(ref["iters"])
+    assert list(res["status"]) == list(ref["status"])
+    ta, tb = res["error_trace"], ref["error_trace"]
+    assert np.array_equal(np.isnan(ta), np.isnan(tb))
+    m = ~np.isnan(tb)
+    np.testing.assert_allclose(ta[m], tb[m], rtol=1e-9)
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+def test_gauss_newton_solve_matches_oracle(engine, oracle, small_wam):
+    p = small_wam
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
+    # size-independent properties: the returned values never have a larger error than the start,
+    # and the reported final error is the graph error of the returned values
+    e0 = engine.graph_error(r, s, p.setting, *_args(p), p.init)
+    ef = engine.graph_error(r, s, p.setting, *_args(p), res["traj"])
+    assert np.all(ef < e0)
+    np.testing.assert_allclose(ef, res["final_error"], rtol=1e-9)
+
+
+def test_fixed_iteration_budget_matches_oracle(engine, oracle, small_wam):
+    p = small_wam
+    st = problems.wam_setting(12, 3, "GN")
+    st.fixed_iterations = 2
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, st, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, st, *_args(p), p.init)
+    assert list(res["iters"]) == [2] * p.B
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
+
+
+def test_planar_arm_with_limits_gn_matches_oracle(engine, oracle):
+    p = problems.arm3_planner()
+    p.setting.setGaussNewton()
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_point_robot_config1_matches_oracle(engine, oracle):
+    p = problems.point_robot_2d()
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_plan_can_be_rerun_and_reused(engine, small_wam):
+    p = small_wam
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    pl = engine.plan(r, s, p.setting, p.B)
+    pl.set_problem(*_args(p), p.init)
+    pl.optimize()
+    a = pl.result()
+    pl.optimize()                       # idempotent: same inputs, same answer
+    b = pl.result()
+    np.testing.assert_array_equal(a["traj"], b["traj"])
+    assert list(a["iters"]) == list(b["iters"])
+    pl.set_problem(p.start_conf, p.start_vel, p.end_conf + 0.05, p.end_vel, p.init)
+    pl.optimize()
+    c = pl.result()
+    assert not np.allclose(a["traj"], c["traj"])
+
+
+def test_full_size_headline_config_properties(engine, oracle):
+    """BASELINE config 3 at full size (WAM, N=100, I=5, 200^3 SDF): too slow to run the oracle on
+    all 64 restarts, so compare 2 restarts exactly and check size-independent properties on all."""
+    p = problems.wam_restarts(B=64)
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    e0 = engine.graph_error(r, s, p.setting, *_args(p), p.init)
+    ef = engine.graph_error(r, s, p.setting, *_args(p), res["traj"])
+    assert np.all(ef < e0)
+    np.testing.assert_allclose(ef, res["final_error"], rtol=1e-9)
+    assert np.all(res["iters"] >= 1)
+    # start / end priors (sigma 1e-4) hold the end points
+    np.testing.assert_allclose(res["traj"][:, 0, :7], p.start_conf, atol=1e-3)
+    np.testing.assert_allclose(res["traj"][:, -1, :7], p.end_conf, atol=1e-3)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    sel = [0, 17]
+    ref = oracle.batch_optimize(ro, so, p.setting, p.start_conf[sel], p.start_vel[sel], p.end_conf[sel],
+                                p.end_vel[sel], p.init[sel], nthreads=2)
+    assert list(res["iters"][sel]) == list(ref["iters"])
+    assert list(res["status"][sel]) == list(ref["status"])
+    np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
+    np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
