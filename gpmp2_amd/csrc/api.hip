@@ -699,7 +699,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * (P.n + 1) * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * (P.n + 1) * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 512));
+  G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 768));
+  G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.prev_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.last_err, B));
@@ -762,8 +763,11 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
     p->timer.begin("linearize", st);
     G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
     p->timer.end(st);
-    p->timer.begin("gn_step", st);
-    G2_TRY(launch_gn_step(P, pb, pass, st));
+    p->timer.begin("assemble", st);
+    G2_TRY(launch_assemble(P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
+    p->timer.end(st);
+    p->timer.begin("gn_step_cr", st);
+    G2_TRY(launch_gn_step_cr(P, pb, pass, st));
     p->timer.end(st);
     G2_HIP(hipMemcpyAsync(p->h_nactive, pb.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
     G2_HIP(hipStreamSynchronize(st));

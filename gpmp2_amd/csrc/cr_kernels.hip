@@ -1,0 +1,443 @@
+// cr_kernels.hip -- the linear-solve half of one Gauss-Newton iteration, restructured for
+// latency (SURVEY.md "hard part: sequential chain"):
+//
+//   k_assemble   : one wavefront per (trajectory, support state).  Builds the block's 16x16 tiles
+//                  from the per-point records (Kronecker weights, appendix A.6) fully in parallel:
+//                  S_i = [D_i | -g_i] for every block and the two couplings H_{i,i-1}, H_{i,i+1}
+//                  for odd blocks (even blocks never use their stride-1 couplings).
+//   k_gn_step_cr : one 1024-thread workgroup (16 wavefronts) per trajectory.  Block cyclic
+//                  reduction = block Cholesky in nested-dissection order: level h eliminates the
+//                  blocks that are odd multiples of h, all in parallel across wavefronts, so the
+//                  dependent chain is log2(N) levels instead of N blocks.  Each elimination is the
+//                  register-resident tile Cholesky of tiles.h; Schur complements and fill-in
+//                  couplings are A^T B tile products on v_mfma_f64_16x16x4_f64.  Also carries the
+//                  gpmp2::optimize control flow (planner/BatchTrajOptimizer.cpp:273-307) and the
+//                  retract.
+#include "assembler.h"
+#include "plan_device.h"
+
+namespace g2 {
+
+constexpr int TILE_DBL = 256;  // doubles per tile (4 registers x 64 lanes)
+
+__device__ __forceinline__ Tile tile_load(const double* p, int lane) {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = p[k * 64 + lane];
+  return T;
+}
+__device__ __forceinline__ void tile_store(double* p, const Tile& T, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) p[k * 64 + lane] = T.r[k];
+}
+__device__ __forceinline__ Tile tile_zero() {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = 0.0;
+  return T;
+}
+
+// =============================================================================== assemble
+template <int D>
+__global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                  const double* __restrict__ traj,
+                                                  const double* __restrict__ rec,
+                                                  const double* __restrict__ gpu,
+                                                  double* __restrict__ tiles,
+                                                  const int* __restrict__ active) {
+  constexpr int n = 2 * D, NG = D * (D + 1) / 2;
+  using Asm = Assembler<D>;
+  const PlanParams& P = *pp;
+  const int N = P.N, I = P.I;
+  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  if (active && !active[b]) return;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  __shared__ typename Asm::Slot slots[2];
+  Asm as(P, pb, rec, gpu, b, lane);
+  as.stage(i, slots[0]);
+  as.stage(i + 1, slots[1]);
+  __syncthreads();
+  const typename Asm::Slot& si = slots[0];
+  const typename Asm::Slot& sn = slots[1];
+  const bool has_prev = i > 0, has_next = i < N, odd = (i & 1) != 0;
+  const double* z = traj + ((size_t)b * (N + 1) + i) * n;
+
+  Tile S, Cl, Cr;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double d = 0.0, hr = 0.0, hl = 0.0;
+    if (as.valid[k]) {
+      const int ar = as.a_row[k], ac = as.a_col, t = as.tri[k];
+      d = (has_prev ? as.KB[k] : 0.0) + (has_next ? as.KA[k] : 0.0);
+      hr = has_next ? as.KO[k] : 0.0;   // H_{i,i+1}[rho][c] = KO[rho][c]
+      hl = has_prev ? as.KOt[k] : 0.0;  // H_{i,i-1}[rho][c] = KO[c][rho]
+      if (!ar && !ac) d += si.pts[I][t];
+      for (int jj = 0; jj < I; jj++) {
+        const GpCoef cf = P.coef[jj];
+        const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
+        const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
+        if (has_prev) {
+          const double Gp = si.pts[jj][t];
+          d = fma(w2r * w2c, Gp, d);
+          hl = fma(w2r * w1c, Gp, hl);  // rows: state i (second), cols: state i-1 (first)
+        }
+        if (has_next) {
+          const double Gn = sn.pts[jj][t];
+          d = fma(w1r * w1c, Gn, d);
+          hr = fma(w1r * w2c, Gn, hr);  // rows: state i (first), cols: state i+1 (second)
+        }
+      }
+    }
+    S.r[k] = d;
+    Cr.r[k] = hr;
+    Cl.r[k] = hl;
+  }
+  // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int rho = g + 4 * k;
+    if (rho >= n) continue;
+    const bool on_diag = (c == rho), on_rhs = (c == RHSCOL);
+    if (!on_diag && !on_rhs) continue;
+    const int ar = as.a_row[k], kr = as.k_row[k];
+    double dd = 0.0, gg = 0.0;
+    const double zz = z[rho];
+    if (i == 0 || i == N) {
+      const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
+      const double w = ar ? P.vel_prior_w : P.conf_prior_w;
+      dd += w;
+      gg += w * (zz - tg[(size_t)b * D + kr]);
+    }
+    double Hh;
+    if (!ar && P.flag_pos_limit) {
+      const double e = hinge_limit(zz, P.pos_lo[kr], P.pos_hi[kr], P.pos_th[kr], Hh);
+      dd += P.pos_w[kr] * Hh * Hh;
+      gg += P.pos_w[kr] * Hh * e;
+    }
+    if (ar && P.flag_vel_limit) {
+      const double e = hinge_limit(zz, -P.vel_lim[kr], P.vel_lim[kr], P.vel_th[kr], Hh);
+      dd += P.vel_w[kr] * Hh * Hh;
+      gg += P.vel_w[kr] * Hh * e;
+    }
+    if (ar && kr == 1 && P.vdyn_w > 0.0) {
+      dd += P.vdyn_w;
+      gg += P.vdyn_w * zz;
+    }
+    if (on_diag) S.r[k] += dd;
+    if (on_rhs) {
+      if (!ar) gg += si.pts[I][NG + kr];
+      for (int jj = 0; jj < I; jj++) {
+        const GpCoef cf = P.coef[jj];
+        if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pts[jj][NG + kr], gg);
+        if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pts[jj][NG + kr], gg);
+      }
+      if (has_next) gg += ar ? (P.delta_t * sn.gp[kr] + sn.gp[D + kr]) : sn.gp[kr];
+      if (has_prev) gg -= si.gp[rho];
+      S.r[k] = -gg;
+    }
+  }
+  double* out = tiles + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
+  tile_store(out, S, lane);
+  if (odd) {
+    tile_store(out + TILE_DBL, Cl, lane);
+    tile_store(out + 2 * TILE_DBL, Cr, lane);
+  }
+}
+
+int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
+                    const double* gpu, const int* active, hipStream_t st) {
+  const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  switch (hp.D) {
+#define G2_ASM_CASE(DD) \
+  case DD: k_assemble<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, rec, gpu, pb.tiles, active); break;
+    G2_ASM_CASE(1) G2_ASM_CASE(2) G2_ASM_CASE(3) G2_ASM_CASE(4) G2_ASM_CASE(5) G2_ASM_CASE(6) G2_ASM_CASE(7)
+#undef G2_ASM_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// =============================================================================== CR elimination
+// Eliminate the n pivots of S = [S | b] (rhs in column RHSCOL) and apply the row operations to
+// the two coupling tiles and to V (identity on entry).  On return
+//   Cl <- R^-T Cl, Cr <- R^-T Cr (both with y = R^-T b copied into column RHSCOL), V <- R^-T.
+template <int n>
+__device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Tile& V, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
+  bool ok = true;
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
+    const int src = gj * 16 + c;
+    const double rowS = __shfl(S.r[rj], src, 64);
+    const double rowL = __shfl(Cl.r[rj], src, 64);
+    const double rowR = __shfl(Cr.r[rj], src, 64);
+    const double rowV = __shfl(V.r[rj], src, 64);
+    const double piv = readlane_d(S.r[rj], gj * 16 + j);
+    ok = ok && (piv > 0.0);
+    const double inv = fast_rcp(piv);
+    if (g == gj) piv_of_row[rj] = piv;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double m = __shfl(S.r[k], g * 16 + j, 64);
+      if (g + 4 * k > j) {
+        const double f = m * inv;
+        S.r[k] = fma(-f, rowS, S.r[k]);
+        Cl.r[k] = fma(-f, rowL, Cl.r[k]);
+        Cr.r[k] = fma(-f, rowR, Cr.r[k]);
+        V.r[k] = fma(-f, rowV, V.r[k]);
+      }
+    }
+  });
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double s = 1.0 / sqrt(piv_of_row[k]);
+    const double y = S.r[k] * s;
+    Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
+    Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
+    V.r[k] *= s;
+  }
+  return ok;
+}
+
+// S -= A^T A restricted to real rows (< n) and to the matrix + rhs columns
+template <int n>
+__device__ __forceinline__ void schur_sub(Tile& S, const Tile& A, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  const Tile T = tile_atb(A, A);
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((g + 4 * k) < n && (c < n || c == RHSCOL)) S.r[k] -= T.r[k];
+}
+// -(A^T B) restricted to the n x n matrix part
+template <int n>
+__device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  Tile T = tile_atb(A, B);
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = ((g + 4 * k) < n && c < n) ? -T.r[k] : 0.0;
+  return T;
+}
+
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row_sum16(double v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// x_j = V^T (y - Wl x_l - Wr x_r); xl / xr = neighbour solutions at this lane's column
+template <int n>
+__device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, const Tile& V, double xl,
+                                               double xr, int lane) {
+  const int c = lane & 15;
+  double t[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double v;
+    if (c == RHSCOL) v = -Wl.r[k];                     // -y (same in both tiles)
+    else v = (c < n) ? fma(Wl.r[k], xl, Wr.r[k] * xr) : 0.0;
+    t[k] = -row_sum16(v);
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) x = fma(V.r[k], t[k], x);
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// =============================================================================== GN step (CR)
+constexpr int CR_WAVES = 16;
+
+template <int D>
+__global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* __restrict__ pp,
+                                                               PlanBuffers pb, int pass) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  if (!pb.active[b]) return;
+  const int N = P.N;
+  const size_t tsz = (size_t)(N + 1) * n;
+  double* cur = pb.cur + b * tsz;
+  double* last = pb.last + b * tsz;
+  double* result = pb.result + b * tsz;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* xs = smem;                       // [N+1][16] solution of each block
+  double* red = smem + (size_t)(N + 1) * 16;  // [CR_WAVES] reduction scratch
+  int* flags = reinterpret_cast<int*>(red + CR_WAVES);  // [0] decision, [1] not-spd
+
+  // ---- graph error at `cur` (all 16 waves), then the gpmp2::optimize control flow
+  {
+    const double* eb = pb.rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+    double acc = 0.0;
+    for (int p = tid; p < P.P; p += blockDim.x) acc += eb[p];
+    const double* gb = pb.gpu + ((size_t)b * (P.n + 1) + P.n) * P.Npad;
+    for (int i = 1 + tid; i <= N; i += blockDim.x) acc += gb[i];
+    acc = wave_sum(acc);
+    if (w == 0) acc += misc_error(P, pb, b, cur, lane);
+    if (lane == 0) red[w] = acc;
+    if (tid == 0) flags[1] = 0;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double tot = 0.0;
+    for (int k = 0; k < CR_WAVES; k++) tot += red[k];
+    const double new_err = 0.5 * tot;
+    int decision = 0;  // 0 iterate, 1 stop(result = cur), 2 stop(result = last)
+    const int it = pb.iters[b];
+    double* tr = pb.trace + (size_t)b * (P.max_iter + 1);
+    if (it <= P.max_iter) tr[it] = new_err;
+    if (pass == 0) {
+      pb.prev_err[b] = new_err;
+      if (P.fixed_iters > 0) decision = 0;
+      else if (new_err <= P.err_tol) { decision = 1; pb.status[b] = GPMP2MI_TRAJ_ALREADY_OPTIMAL; }
+      else if (P.max_iter <= 0) { decision = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; }
+    } else if (P.fixed_iters > 0) {
+      if (it >= P.fixed_iters) { decision = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; }
+    } else {
+      const double prev = pb.prev_err[b];
+      const bool conv = check_convergence(P.rel_thresh, P.abs_tol, P.err_tol, prev, new_err);
+      if (it < P.max_iter && !conv) {
+        pb.prev_err[b] = new_err;
+      } else if (new_err > prev && P.no_increase) {
+        decision = 2;
+        pb.status[b] = GPMP2MI_TRAJ_ROLLED_BACK;
+        pb.final_err[b] = prev;
+      } else {
+        decision = 1;
+        pb.status[b] = conv ? GPMP2MI_TRAJ_CONVERGED : GPMP2MI_TRAJ_MAX_ITER;
+      }
+    }
+    if (decision == 1) pb.final_err[b] = new_err;
+    pb.cur_err[b] = new_err;
+    flags[0] = decision;
+  }
+  __syncthreads();
+  const int decision = flags[0];
+  if (decision != 0) {
+    const double* src = (decision == 2) ? last : cur;
+    for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = src[k];
+    if (tid == 0) pb.active[b] = 0;
+    return;
+  }
+
+  // ---- forward: block cyclic reduction
+  const double* tiles = pb.tiles + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
+  bool ok = true;
+  int hfinal = 1;
+  while (hfinal <= N) hfinal <<= 1;
+  for (int h = 1; h <= hfinal; h <<= 1) {
+    const bool final = (h == hfinal);
+    const int count = final ? 1 : ((N / h) + 1) / 2;
+    for (int idx = w; idx < count; idx += CR_WAVES) {
+      const int j = final ? 0 : h * (2 * idx + 1);
+      Tile S = tile_load(tiles + (size_t)j * 3 * TILE_DBL, lane);
+      Tile Cl, Cr;
+      if (h == 1) {
+        Cl = tile_load(tiles + (size_t)j * 3 * TILE_DBL + TILE_DBL, lane);
+        Cr = tile_load(tiles + (size_t)j * 3 * TILE_DBL + 2 * TILE_DBL, lane);
+      } else {
+        Cl = tile_zero();
+        Cr = tile_zero();
+        // deferred Schur complements of every lower level, fill-in couplings from level h/2
+        for (int hh = 1; hh < h; hh <<= 1) {
+          const int jm = j - hh, jp = j + hh;
+          const bool top = (hh == (h >> 1)) && !final;
+          if (jm >= 0) {
+            const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
+            schur_sub<n>(S, Wr, lane);
+            if (top) {
+              const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
+              Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
+            }
+          }
+          if (jp <= N) {
+            const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
+            schur_sub<n>(S, Wl, lane);
+            if (top && j + h <= N) {
+              const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
+              Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
+            }
+          }
+        }
+      }
+      Tile V;
+#pragma unroll
+      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+      ok = tile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
+      double* f = fac + (size_t)j * 3 * TILE_DBL;
+      tile_store(f, Cl, lane);
+      tile_store(f + TILE_DBL, Cr, lane);
+      tile_store(f + 2 * TILE_DBL, V, lane);
+    }
+    __syncthreads();
+  }
+  if (!ok && lane == 0) flags[1] = 1;
+  __syncthreads();
+  if (flags[1]) {
+    for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
+    if (tid == 0) {
+      pb.status[b] = GPMP2MI_TRAJ_NOT_SPD;
+      pb.final_err[b] = pb.cur_err[b];
+      pb.active[b] = 0;
+    }
+    return;
+  }
+
+  // ---- backward: same tree, top down
+  for (int h = hfinal; h >= 1; h >>= 1) {
+    const bool final = (h == hfinal);
+    const int count = final ? 1 : ((N / h) + 1) / 2;
+    for (int idx = w; idx < count; idx += CR_WAVES) {
+      const int j = final ? 0 : h * (2 * idx + 1);
+      const double* f = fac + (size_t)j * 3 * TILE_DBL;
+      const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
+      const int jl = j - h, jr = j + h;
+      const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
+      const double xr = (!final && jr <= N) ? xs[jr * 16 + c] : 0.0;
+      const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+      if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
+    }
+    __syncthreads();
+  }
+
+  // ---- last = cur ; cur = retract(cur, delta)
+  for (size_t k = tid; k < tsz; k += blockDim.x) {
+    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+    const double v = cur[k];
+    last[k] = v;
+    cur[k] = v + xs[i * 16 + rho];
+  }
+  if (tid == 0) {
+    pb.last_err[b] = pb.cur_err[b];
+    pb.iters[b] += 1;
+    atomicAdd(pb.n_active, 1);
+  }
+}
+
+int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {
+  const dim3 grid(hp.B), block(64 * CR_WAVES);
+  const size_t shmem = ((size_t)(hp.N + 1) * 16 + CR_WAVES + 2) * sizeof(double);
+  if (shmem > 150 * 1024) {
+    set_error("total_step too large for the LDS-resident solution buffer");
+    return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  switch (hp.D) {
+#define G2_CR_CASE(DD) \
+  case DD: k_gn_step_cr<DD><<<grid, block, shmem, st>>>(pb.params, pb, pass); break;
+    G2_CR_CASE(1) G2_CR_CASE(2) G2_CR_CASE(3) G2_CR_CASE(4) G2_CR_CASE(5) G2_CR_CASE(6) G2_CR_CASE(7)
+#undef G2_CR_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+}  // namespace g2

@@ -43,7 +43,8 @@ struct PlanBuffers {
   double* rec2;            // second buffer for trial linearizations (LM / Dogleg)
   double* gpu;             // [B][n+1][Npad] GP prior W r (n) and r^T W r, per interval end state
   double* gpu2;
-  double* fac;             // [B][N+1][2][4][64] factor tiles (V = R^-T, W|y) for back-substitution
+  double* tiles;           // [B][N+1][3][256] assembled tiles: S=[D|-g], H_{i,i-1}, H_{i,i+1} (odd i)
+  double* fac;             // [B][N+1][3][256] factor tiles Wl, Wr (both carry y), V = R^-T
   double* delta;           // [B][N+1][2D]
   double* dx_u;            // Dogleg steepest-descent point
   // per-trajectory scalars
@@ -64,7 +65,9 @@ int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev
                      const PlanParams& hp, const PlanBuffers& pb, const double* traj, double* rec,
                      double* gpu, const int* active, hipStream_t st);
 int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
-int launch_gn_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
+int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
+                    const double* gpu, const int* active, hipStream_t st);
+int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
                         const double* rec, const double* gpu, double* err, hipStream_t st);
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj,

@@ -1,0 +1,63 @@
+// plan_device.h -- device helpers shared by the plan kernels: graph-error terms and the
+// gtsam::checkConvergence rule.
+#pragma once
+#include "device_math.h"
+#include "plan.h"
+#include "tiles.h"
+
+namespace g2 {
+
+// =============================================================================== error terms
+// prior + limit + vehicle-dynamics error of one trajectory (0.5 * whitened squared residuals),
+// wave-reduced.  PriorFactor (planner/BatchTrajOptimizer-inl.h:41-48), JointLimitFactorVector,
+// VelocityLimitFactorVector (:50-59), VehicleDynamicsFactor (dynamics/VehicleDynamics.h:19-27).
+__device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuffers& pb, int b,
+                                             const double* __restrict__ tr, int lane) {
+  const int D = P.D, n = P.n, N = P.N;
+  double acc = 0.0;
+  for (int idx = lane; idx < (N + 1) * n; idx += 64) {
+    const int i = idx / n, rho = idx - i * n;
+    const int a = rho >= D, k = rho - a * D;
+    const double z = tr[idx];
+    if (i == 0 || i == N) {
+      const double* tg = (i == 0) ? (a ? pb.start_vel : pb.start_conf) : (a ? pb.end_vel : pb.end_conf);
+      const double d = z - tg[(size_t)b * D + k];
+      acc += (a ? P.vel_prior_w : P.conf_prior_w) * d * d;
+    }
+    double H;
+    if (!a && P.flag_pos_limit) {
+      const double e = hinge_limit(z, P.pos_lo[k], P.pos_hi[k], P.pos_th[k], H);
+      acc += P.pos_w[k] * e * e;
+    }
+    if (a && P.flag_vel_limit) {
+      const double e = hinge_limit(z, -P.vel_lim[k], P.vel_lim[k], P.vel_th[k], H);
+      acc += P.vel_w[k] * e * e;
+    }
+    if (a && k == 1 && P.vdyn_w > 0.0) acc += P.vdyn_w * z * z;
+  }
+  return wave_sum(acc);
+}
+
+// total graph error of trajectory b from its point records: 0.5 * (sum e_p + sum gp energy + misc)
+__device__ __forceinline__ double total_error(const PlanParams& P, const PlanBuffers& pb, int b,
+                                              const double* __restrict__ tr,
+                                              const double* __restrict__ rec,
+                                              const double* __restrict__ gpu, int lane) {
+  const double* eb = rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+  double acc = 0.0;
+  for (int p = lane; p < P.P; p += 64) acc += eb[p];
+  const double* gb = gpu + ((size_t)b * (P.n + 1) + P.n) * P.Npad;
+  for (int i = 1 + lane; i <= P.N; i += 64) acc += gb[i];
+  return 0.5 * (wave_sum(acc) + misc_error(P, pb, b, tr, lane));
+}
+
+__device__ __forceinline__ bool check_convergence(double rel, double abs_, double err_tol, double cur,
+                                                  double nw) {
+  if (nw <= err_tol) return true;
+  const double abs_dec = cur - nw;
+  const double rel_dec = abs_dec / cur;
+  return (rel != 0.0 && rel_dec <= rel) || (abs_dec <= abs_);
+}
+
+
+}  // namespace g2
