@@ -212,7 +212,8 @@ struct gpmp2mi_plan {
   PlanParams hp;
   PlanBuffers pb;
   std::vector<void*> allocs;
-  int* h_nactive = nullptr;  // pinned
+  int* h_nactive = nullptr;  // pinned [2]
+  hipEvent_t ev[2] = {nullptr, nullptr};
   KernelTimer timer;
   bool problem_set = false;
   bool optimized = false;
@@ -699,7 +700,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * (P.n + 1) * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * (P.n + 1) * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 768));
+  G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256));
   G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.prev_err, B));
@@ -711,8 +712,12 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.status, B));
   G2_TRY(plan_alloc(p.get(), &pb.active, B));
   G2_TRY(plan_alloc(p.get(), &pb.phase, B));
+  G2_TRY(plan_alloc(p.get(), &pb.notspd, B));
   G2_TRY(plan_alloc(p.get(), &pb.n_active, 1));
-  G2_HIP(hipHostMalloc((void**)&p->h_nactive, sizeof(int), hipHostMallocDefault));
+  G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
+  G2_HIP(hipHostMalloc((void**)&p->h_nactive, 2 * sizeof(int), hipHostMallocDefault));
+  G2_HIP(hipEventCreateWithFlags(&p->ev[0], hipEventDisableTiming));
+  G2_HIP(hipEventCreateWithFlags(&p->ev[1], hipEventDisableTiming));
   *out = p.release();
   return GPMP2MI_OK;
 }
@@ -721,6 +726,8 @@ void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
   if (p->h_nactive) (void)hipHostFree(p->h_nactive);
+  for (auto e : p->ev)
+    if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -758,7 +765,11 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   G2_HIP(hipMemcpyAsync(pb.cur, pb.trial, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
   G2_TRY(launch_plan_reset(P, pb, st));
   const int max_pass = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 1;
+  // Software-pipelined driver: pass k+1 is enqueued before the host looks at the active count of
+  // pass k, so the GPU never waits for the host.  When pass k turns out to have finished every
+  // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
   for (int pass = 0; pass < max_pass; pass++) {
+    const int slot = pass & 1;
     G2_HIP(hipMemsetAsync(pb.n_active, 0, sizeof(int), st));
     p->timer.begin("linearize", st);
     G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
@@ -769,9 +780,12 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
     p->timer.begin("gn_step_cr", st);
     G2_TRY(launch_gn_step_cr(P, pb, pass, st));
     p->timer.end(st);
-    G2_HIP(hipMemcpyAsync(p->h_nactive, pb.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
-    G2_HIP(hipStreamSynchronize(st));
-    if (*p->h_nactive == 0) break;
+    G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    G2_HIP(hipEventRecord(p->ev[slot], st));
+    if (pass >= 1) {
+      G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
+      if (p->h_nactive[slot ^ 1] == 0) break;
+    }
   }
   G2_HIP(hipStreamSynchronize(st));
   if (p->timer.enabled) p->timer.collect();
@@ -869,6 +883,26 @@ int gpmp2mi_collision_cost(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, int tot
       for (int k = 0; k < S; k++) c += err[((size_t)b * (total_step + 1) + i) * S + k];
     cost[b] = c;
   }
+  return GPMP2MI_OK;
+}
+
+// diagnostic: raw s_memtime stamps of the last step kernel (all zero unless built with -DG2_STAMPS)
+int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64) {
+  G2_CHECK(p && out64 && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_HIP(hipMemcpy(out64, p->pb.stamps + (size_t)b * 64, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return GPMP2MI_OK;
+}
+
+// diagnostic: out[8][64] = {bcast_row<0..3>, bcast_in_row<5>, row_sum16, sum_rows, bcast_in_row<13>}(in[64])
+int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
+  G2_CHECK(in64 && out512, GPMP2MI_ERR_INVALID, "null argument");
+  G2_TRY(ensure_device());
+  DevBuf<double> di, dout;
+  G2_TRY(di.upload(in64, 64));
+  G2_TRY(dout.alloc(512));
+  G2_TRY(launch_debug_crosslane(di.p, dout.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(dout.download(out512));
   return GPMP2MI_OK;
 }
 

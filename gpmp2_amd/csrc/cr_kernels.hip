@@ -37,6 +37,72 @@ __device__ __forceinline__ Tile tile_zero() {
   return T;
 }
 
+// =============================================================================== CR elimination
+// Eliminate the n pivots of S = [S | b] (rhs in column RHSCOL) and apply the row operations to
+// the two coupling tiles and to V (identity on entry).  On return
+//   Cl <- R^-T Cl, Cr <- R^-T Cr (both with y = R^-T b copied into column RHSCOL), V <- R^-T.
+#ifndef G2_M_DPP
+#define G2_M_DPP 1
+#endif
+// measured on MI355X (profiles/r01_cr_variants.txt): pivot-row broadcast through ds_bpermute beats
+// the permlane-swap form (48k vs 80k cycles at the widest level); the in-row multiplier broadcast
+// is DPP row_newbcast either way.
+#ifndef G2_ROW_SWAP
+#define G2_ROW_SWAP 0
+#endif
+#ifndef G2_SUM_DPP
+#define G2_SUM_DPP 1
+#endif
+template <int n>
+__device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Tile& V, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
+  bool ok = true;
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
+#if G2_ROW_SWAP
+    const double rowS = bcast_row<gj>(S.r[rj]);
+    const double rowL = bcast_row<gj>(Cl.r[rj]);
+    const double rowR = bcast_row<gj>(Cr.r[rj]);
+    const double rowV = bcast_row<gj>(V.r[rj]);
+#else
+    const int src = gj * 16 + c;
+    const double rowS = __shfl(S.r[rj], src, 64);
+    const double rowL = __shfl(Cl.r[rj], src, 64);
+    const double rowR = __shfl(Cr.r[rj], src, 64);
+    const double rowV = __shfl(V.r[rj], src, 64);
+#endif
+    const double piv = readlane_d(S.r[rj], gj * 16 + j);
+    ok = ok && (piv > 0.0);
+    const double inv = fast_rcp(piv);
+    if (g == gj) piv_of_row[rj] = piv;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (4 * k + 3 <= j) continue;  // rows g + 4k <= j for every g: nothing below the pivot here
+#if G2_M_DPP
+      const double m = bcast_in_row<j>(S.r[k]);
+#else
+      const double m = __shfl(S.r[k], g * 16 + j, 64);
+#endif
+      // rows at or above the pivot get a zero multiplier instead of a divergent branch
+      const double f = (g + 4 * k > j) ? m * inv : 0.0;
+      S.r[k] = fma(-f, rowS, S.r[k]);
+      Cl.r[k] = fma(-f, rowL, Cl.r[k]);
+      Cr.r[k] = fma(-f, rowR, Cr.r[k]);
+      V.r[k] = fma(-f, rowV, V.r[k]);
+    }
+  });
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double s = 1.0 / sqrt(piv_of_row[k]);
+    const double y = S.r[k] * s;
+    Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
+    Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
+    V.r[k] *= s;
+  }
+  return ok;
+}
+
 // =============================================================================== assemble
 template <int D>
 __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
@@ -136,11 +202,20 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
       S.r[k] = -gg;
     }
   }
-  double* out = tiles + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
-  tile_store(out, S, lane);
-  if (odd) {
-    tile_store(out + TILE_DBL, Cl, lane);
-    tile_store(out + 2 * TILE_DBL, Cr, lane);
+  if (!odd) {
+    tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
+  } else {
+    // level h = 1 of the cyclic reduction: odd blocks only couple to their (even) neighbours, so
+    // they are eliminated right here, spread over the whole chip instead of one CU per trajectory
+    Tile V;
+#pragma unroll
+    for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+    const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
+    double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
+    tile_store(f, Cl, lane);
+    tile_store(f + TILE_DBL, Cr, lane);
+    tile_store(f + 2 * TILE_DBL, V, lane);
+    if (!ok && lane == 0) pb.notspd[b] = 1;
   }
 }
 
@@ -158,49 +233,6 @@ int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* t
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
-}
-
-// =============================================================================== CR elimination
-// Eliminate the n pivots of S = [S | b] (rhs in column RHSCOL) and apply the row operations to
-// the two coupling tiles and to V (identity on entry).  On return
-//   Cl <- R^-T Cl, Cr <- R^-T Cr (both with y = R^-T b copied into column RHSCOL), V <- R^-T.
-template <int n>
-__device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Tile& V, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
-  bool ok = true;
-  static_for<0, n>([&](auto jc) {
-    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
-    const int src = gj * 16 + c;
-    const double rowS = __shfl(S.r[rj], src, 64);
-    const double rowL = __shfl(Cl.r[rj], src, 64);
-    const double rowR = __shfl(Cr.r[rj], src, 64);
-    const double rowV = __shfl(V.r[rj], src, 64);
-    const double piv = readlane_d(S.r[rj], gj * 16 + j);
-    ok = ok && (piv > 0.0);
-    const double inv = fast_rcp(piv);
-    if (g == gj) piv_of_row[rj] = piv;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const double m = __shfl(S.r[k], g * 16 + j, 64);
-      if (g + 4 * k > j) {
-        const double f = m * inv;
-        S.r[k] = fma(-f, rowS, S.r[k]);
-        Cl.r[k] = fma(-f, rowL, Cl.r[k]);
-        Cr.r[k] = fma(-f, rowR, Cr.r[k]);
-        V.r[k] = fma(-f, rowV, V.r[k]);
-      }
-    }
-  });
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const double s = 1.0 / sqrt(piv_of_row[k]);
-    const double y = S.r[k] * s;
-    Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
-    Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
-    V.r[k] *= s;
-  }
-  return ok;
 }
 
 // S -= A^T A restricted to real rows (< n) and to the matrix + rhs columns
@@ -224,9 +256,13 @@ __device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane)
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
 __device__ __forceinline__ double row_sum16(double v) {
+#if G2_SUM_DPP
+  return row_sum16_dpp(v);
+#else
 #pragma unroll
   for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
+#endif
 }
 
 // x_j = V^T (y - Wl x_l - Wr x_r); xl / xr = neighbour solutions at this lane's column
@@ -245,13 +281,31 @@ __device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, c
   double x = 0.0;
 #pragma unroll
   for (int k = 0; k < 4; k++) x = fma(V.r[k], t[k], x);
+#if G2_SUM_DPP
+  return sum_rows(x);
+#else
   x += __shfl_xor(x, 16, 64);
   x += __shfl_xor(x, 32, 64);
   return x;
+#endif
 }
 
 // =============================================================================== GN step (CR)
-constexpr int CR_WAVES = 16;
+#ifndef G2_CR_WAVES
+#define G2_CR_WAVES 16
+#endif
+constexpr int CR_WAVES = G2_CR_WAVES;
+
+// Diagnostic build only (-DG2_STAMPS): s_memtime stamps of one workgroup's phases, written to a
+// buffer nothing else reads (cdna_hip_programming.md section 7 "In-kernel stamps").
+#ifdef G2_STAMPS
+#define G2_STAMP(k)                                                          \
+  do {                                                                       \
+    if (tid == 0 && (k) < 64) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define G2_STAMP(k) do {} while (0)
+#endif
 
 template <int D>
 __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* __restrict__ pp,
@@ -270,6 +324,7 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
   double* red = smem + (size_t)(N + 1) * 16;  // [CR_WAVES] reduction scratch
   int* flags = reinterpret_cast<int*>(red + CR_WAVES);  // [0] decision, [1] not-spd
 
+  G2_STAMP(0);
   // ---- graph error at `cur` (all 16 waves), then the gpmp2::optimize control flow
   {
     const double* eb = pb.rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
@@ -325,46 +380,47 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
     return;
   }
 
-  // ---- forward: block cyclic reduction
-  const double* tiles = pb.tiles + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  G2_STAMP(1);
+  // ---- forward: block cyclic reduction.  Level h = 1 (odd blocks) was done by k_assemble.
+  // Phase h >= 2: every block that is still active (multiple of h) absorbs the Schur complements
+  // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
+  // updated diagonal tile back (U tasks, done by the wavefronts that have no E task).
+  int stamp_k = 2;
+  double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
   double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  for (int h = 1; h <= hfinal; h <<= 1) {
+  for (int h = 2; h <= hfinal; h <<= 1) {
     const bool final = (h == hfinal);
-    const int count = final ? 1 : ((N / h) + 1) / 2;
-    for (int idx = w; idx < count; idx += CR_WAVES) {
-      const int j = final ? 0 : h * (2 * idx + 1);
-      Tile S = tile_load(tiles + (size_t)j * 3 * TILE_DBL, lane);
-      Tile Cl, Cr;
-      if (h == 1) {
-        Cl = tile_load(tiles + (size_t)j * 3 * TILE_DBL + TILE_DBL, lane);
-        Cr = tile_load(tiles + (size_t)j * 3 * TILE_DBL + 2 * TILE_DBL, lane);
-      } else {
-        Cl = tile_zero();
-        Cr = tile_zero();
-        // deferred Schur complements of every lower level, fill-in couplings from level h/2
-        for (int hh = 1; hh < h; hh <<= 1) {
-          const int jm = j - hh, jp = j + hh;
-          const bool top = (hh == (h >> 1)) && !final;
-          if (jm >= 0) {
-            const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
-            schur_sub<n>(S, Wr, lane);
-            if (top) {
-              const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
-              Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
-            }
-          }
-          if (jp <= N) {
-            const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
-            schur_sub<n>(S, Wl, lane);
-            if (top && j + h <= N) {
-              const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
-              Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
-            }
-          }
+    const int hh = h >> 1;
+    const int countE = final ? 1 : ((N / h) + 1) / 2;
+    const int countU = final ? 0 : (N / (2 * h)) + 1;  // multiples of 2h in [0, N]
+    for (int idx = w; idx < countE + countU; idx += CR_WAVES) {
+      const bool elim = idx < countE;
+      const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
+      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
+      Tile Cl = tile_zero(), Cr = tile_zero();
+      const int jm = j - hh, jp = j + hh;
+      if (jm >= 0) {
+        const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
+        schur_sub<n>(S, Wr, lane);
+        if (elim && !final) {
+          const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
+          Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
         }
+      }
+      if (jp <= N) {
+        const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
+        schur_sub<n>(S, Wl, lane);
+        if (elim && !final && j + h <= N) {
+          const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
+          Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
+        }
+      }
+      if (!elim) {
+        tile_store(tiles + (size_t)j * TILE_DBL, S, lane);
+        continue;
       }
       Tile V;
 #pragma unroll
@@ -376,10 +432,13 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
       tile_store(f + 2 * TILE_DBL, V, lane);
     }
     __syncthreads();
+    G2_STAMP(stamp_k);
+    stamp_k++;
   }
-  if (!ok && lane == 0) flags[1] = 1;
+  if ((!ok && lane == 0) || (tid == 0 && pb.notspd[b])) flags[1] = 1;
   __syncthreads();
   if (flags[1]) {
+    if (tid == 0) pb.notspd[b] = 0;
     for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
     if (tid == 0) {
       pb.status[b] = GPMP2MI_TRAJ_NOT_SPD;
@@ -404,6 +463,8 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
       if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
     }
     __syncthreads();
+    G2_STAMP(stamp_k);
+    stamp_k++;
   }
 
   // ---- last = cur ; cur = retract(cur, delta)
@@ -413,6 +474,7 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
     last[k] = v;
     cur[k] = v + xs[i * 16 + rho];
   }
+  G2_STAMP(stamp_k);
   if (tid == 0) {
     pb.last_err[b] = pb.cur_err[b];
     pb.iters[b] += 1;
@@ -436,6 +498,26 @@ int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hip
       set_error("block solver is instantiated for dof <= 7");
       return GPMP2MI_ERR_UNSUPPORTED;
   }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+
+// diagnostic: exercises the cross-lane helpers so tests can pin their lane semantics on hardware
+__global__ void k_debug_crosslane(const double* __restrict__ in, double* __restrict__ out) {
+  const int l = threadIdx.x;
+  const double v = in[l];
+  out[0 * 64 + l] = bcast_row<0>(v);
+  out[1 * 64 + l] = bcast_row<1>(v);
+  out[2 * 64 + l] = bcast_row<2>(v);
+  out[3 * 64 + l] = bcast_row<3>(v);
+  out[4 * 64 + l] = bcast_in_row<5>(v);
+  out[5 * 64 + l] = row_sum16_dpp(v);
+  out[6 * 64 + l] = sum_rows(v);
+  out[7 * 64 + l] = bcast_in_row<13>(v);
+}
+int launch_debug_crosslane(const double* in, double* out, hipStream_t st) {
+  k_debug_crosslane<<<dim3(1), dim3(64), 0, st>>>(in, out);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

@@ -43,7 +43,7 @@ struct PlanBuffers {
   double* rec2;            // second buffer for trial linearizations (LM / Dogleg)
   double* gpu;             // [B][n+1][Npad] GP prior W r (n) and r^T W r, per interval end state
   double* gpu2;
-  double* tiles;           // [B][N+1][3][256] assembled tiles: S=[D|-g], H_{i,i-1}, H_{i,i+1} (odd i)
+  double* tiles;           // [B][N+1][256] diagonal tile S_i = [D_i | -g_i] of every even block (updated in place)
   double* fac;             // [B][N+1][3][256] factor tiles Wl, Wr (both carry y), V = R^-T
   double* delta;           // [B][N+1][2D]
   double* dx_u;            // Dogleg steepest-descent point
@@ -58,7 +58,9 @@ struct PlanBuffers {
   int* status;
   int* active;             // 1 while the trajectory is still iterating
   int* phase;              // optimizer-specific sub-state
+  int* notspd;             // [B] set when a level-1 pivot (k_assemble) was not positive
   int* n_active;           // [1] device counter
+  unsigned long long* stamps;  // [B][64] s_memtime stamps (diagnostic builds only)
 };
 
 int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
@@ -67,6 +69,7 @@ int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev
 int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
                     const double* gpu, const int* active, hipStream_t st);
+int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
                         const double* rec, const double* gpu, double* err, hipStream_t st);

@@ -176,6 +176,7 @@ __global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) 
   pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
   pb.active[b] = 1;
   pb.phase[b] = 0;
+  pb.notspd[b] = 0;
   pb.cur_err[b] = pb.prev_err[b] = pb.last_err[b] = pb.final_err[b] = 0.0;
   pb.lambda[b] = (P.opt_type == GPMP2MI_OPT_DOGLEG) ? P.dl_delta0 : P.lm_lambda0;
   double* tr = pb.trace + (size_t)b * (P.max_iter + 1);

@@ -38,6 +38,58 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// =============================================================================== cross-lane moves
+// All VALU (no LDS): gfx950 v_permlane16_swap / v_permlane32_swap for moves between the four
+// 16-lane rows of a wavefront, DPP row_newbcast / row_ror for moves inside a row.
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+
+// value held by row G (lanes 16G .. 16G+15), broadcast to all four rows (same column)
+template <int G>
+__device__ __forceinline__ unsigned bcast_row_u32(unsigned x) {
+  const u2v a = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // [r0,r0,r2,r2], [r1,r1,r3,r3]
+  const unsigned y = (G & 1) ? a[1] : a[0];
+  const u2v b = __builtin_amdgcn_permlane32_swap(y, y, false, false);  // [lo,lo], [hi,hi]
+  return (G & 2) ? b[1] : b[0];
+}
+template <int G>
+__device__ __forceinline__ double bcast_row(double v) {
+  return __hiloint2double((int)bcast_row_u32<G>((unsigned)__double2hiint(v)),
+                          (int)bcast_row_u32<G>((unsigned)__double2loint(v)));
+}
+// value held by lane J of each row, broadcast inside that row (DPP row_newbcast:J)
+template <int J>
+__device__ __forceinline__ double bcast_in_row(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+template <int R>
+__device__ __forceinline__ double dpp_row_ror(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + R, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + R, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// sum over the 16 lanes of each row, result in every lane of the row
+__device__ __forceinline__ double row_sum16_dpp(double v) {
+  v += dpp_row_ror<8>(v);
+  v += dpp_row_ror<4>(v);
+  v += dpp_row_ror<2>(v);
+  v += dpp_row_ror<1>(v);
+  return v;
+}
+// sum over the four rows (same column), result in every row
+__device__ __forceinline__ double sum_rows(double v) {
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  u2v a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  u2v b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double t = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+  lo = (unsigned)__double2loint(t);
+  hi = (unsigned)__double2hiint(t);
+  a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
+
 // =============================================================================== 16x16 tiles
 // A tile is a 16x16 fp64 matrix spread over one wavefront in the accumulator layout of
 // v_mfma_f64_16x16x4_f64: lane l holds column c = l & 15 and rows rho = (l >> 4) + 4 k in r[k].

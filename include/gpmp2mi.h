@@ -292,6 +292,10 @@ int gpmp2mi_version(void);
  * stream): names[i] / ms[i] / launches[i] for i < *n.  Used by bench.py for the roofline line. */
 int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable);
 int gpmp2mi_plan_get_timing(gpmp2mi_plan* p, int* n, const char** names, double* ms, int* launches);
+/* Diagnostic builds (-DG2_STAMPS) only: 64 raw s_memtime stamps of trajectory b's last solve step. */
+int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64);
+/* Diagnostic: lane semantics of the wave-level moves the solver relies on (tests/test_gpu_plan.py). */
+int gpmp2mi_debug_crosslane(const double* in64, double* out512);
 
 #ifdef __cplusplus
 }

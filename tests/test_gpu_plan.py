@@ -194,3 +194,20 @@ def test_full_size_headline_config_properties(engine, oracle):
     assert list(res["status"][sel]) == list(ref["status"])
     np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
     np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
+
+
+def test_crosslane_primitives(engine):
+    """Pins the lane semantics of the gfx950 moves the tile solver is built on
+    (v_permlane16_swap / v_permlane32_swap, DPP row_newbcast / row_ror)."""
+    import ctypes as C
+    from gpmp2_amd._capi import dptr
+    v = np.random.default_rng(11).normal(size=64)
+    out = np.zeros((8, 64))
+    engine._ck(engine.lib.gpmp2mi_debug_crosslane(dptr(v), dptr(out)))
+    rows = v.reshape(4, 16)
+    for gsel in range(4):
+        np.testing.assert_array_equal(out[gsel].reshape(4, 16), np.tile(rows[gsel], (4, 1)))
+    np.testing.assert_array_equal(out[4].reshape(4, 16), np.repeat(rows[:, 5:6], 16, axis=1))
+    np.testing.assert_array_equal(out[7].reshape(4, 16), np.repeat(rows[:, 13:14], 16, axis=1))
+    np.testing.assert_allclose(out[5].reshape(4, 16), np.repeat(rows.sum(axis=1, keepdims=True), 16, axis=1), atol=1e-14)
+    np.testing.assert_allclose(out[6].reshape(4, 16), np.tile(rows.sum(axis=0), (4, 1)), atol=1e-14)
