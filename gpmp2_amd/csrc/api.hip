@@ -143,10 +143,13 @@ struct gpmp2mi_sdf {
 };
 
 struct KernelTimer {
+  // One HIP event per kernel boundary on the launch stream: mark(name) is recorded right before
+  // kernel `name`, close() after the last kernel of a pass; a kernel's time is the distance to the
+  // next mark.
   bool enabled = false;
   struct Rec {
-    const char* name;
-    hipEvent_t a, b;
+    const char* name;  // nullptr = closing mark
+    hipEvent_t ev;
   };
   std::vector<Rec> recs;
   std::vector<std::string> names;
@@ -165,14 +168,12 @@ struct KernelTimer {
   }
   void begin(const char* name, hipStream_t st) {
     if (!enabled) return;
-    Rec r{name, get(), get()};
-    (void)hipEventRecord(r.a, st);
+    Rec r{name, get()};
+    (void)hipEventRecord(r.ev, st);
     recs.push_back(r);
   }
-  void end(hipStream_t st) {
-    if (!enabled) return;
-    (void)hipEventRecord(recs.back().b, st);
-  }
+  void end(hipStream_t) {}
+  void close(hipStream_t st) { begin(nullptr, st); }
   void reset() {
     recs.clear();
     pool_used = 0;
@@ -184,14 +185,15 @@ struct KernelTimer {
     names.clear();
     ms.clear();
     launches.clear();
-    for (auto& r : recs) {
+    for (size_t i = 0; i + 1 < recs.size(); i++) {
+      if (!recs[i].name) continue;
       float t = 0;
-      if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+      if (hipEventElapsedTime(&t, recs[i].ev, recs[i + 1].ev) != hipSuccess) continue;
       size_t k = 0;
       for (; k < names.size(); k++)
-        if (names[k] == r.name) break;
+        if (names[k] == recs[i].name) break;
       if (k == names.size()) {
-        names.push_back(r.name);
+        names.push_back(recs[i].name);
         ms.push_back(0.0);
         launches.push_back(0);
       }
@@ -713,7 +715,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.active, B));
   G2_TRY(plan_alloc(p.get(), &pb.phase, B));
   G2_TRY(plan_alloc(p.get(), &pb.notspd, B));
-  G2_TRY(plan_alloc(p.get(), &pb.n_active, 1));
+  G2_TRY(plan_alloc(p.get(), &pb.epart, (size_t)B * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.n_active, (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 2));
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
   G2_HIP(hipHostMalloc((void**)&p->h_nactive, 2 * sizeof(int), hipHostMallocDefault));
   G2_HIP(hipEventCreateWithFlags(&p->ev[0], hipEventDisableTiming));
@@ -770,7 +773,6 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
   for (int pass = 0; pass < max_pass; pass++) {
     const int slot = pass & 1;
-    G2_HIP(hipMemsetAsync(pb.n_active, 0, sizeof(int), st));
     p->timer.begin("linearize", st);
     G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
     p->timer.end(st);
@@ -779,8 +781,8 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
     p->timer.end(st);
     p->timer.begin("gn_step_cr", st);
     G2_TRY(launch_gn_step_cr(P, pb, pass, st));
-    p->timer.end(st);
-    G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active, sizeof(int), hipMemcpyDeviceToHost, st));
+    p->timer.close(st);
+    G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
     G2_HIP(hipEventRecord(p->ev[slot], st));
     if (pass >= 1) {
       G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));

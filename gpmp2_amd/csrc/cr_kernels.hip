@@ -158,6 +158,11 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
     Cr.r[k] = hr;
     Cl.r[k] = hl;
   }
+  // this block's share of the graph error: unary point of state i, the interpolated points and the
+  // GP prior of the interval ending at i, plus (below) the prior / limit / dynamics terms of state i
+  double err_acc = 0.0;
+  if (lane <= I && (lane == I || has_prev)) err_acc = si.pts[lane][NG + D];
+  if (lane == 63 && has_prev) err_acc += si.gp[n];
   // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -166,30 +171,38 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
     const bool on_diag = (c == rho), on_rhs = (c == RHSCOL);
     if (!on_diag && !on_rhs) continue;
     const int ar = as.a_row[k], kr = as.k_row[k];
-    double dd = 0.0, gg = 0.0;
+    double dd = 0.0, gg = 0.0, ee = 0.0;
     const double zz = z[rho];
     if (i == 0 || i == N) {
       const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
       const double w = ar ? P.vel_prior_w : P.conf_prior_w;
+      const double dz = zz - tg[(size_t)b * D + kr];
       dd += w;
-      gg += w * (zz - tg[(size_t)b * D + kr]);
+      gg += w * dz;
+      ee += w * dz * dz;
     }
     double Hh;
     if (!ar && P.flag_pos_limit) {
       const double e = hinge_limit(zz, P.pos_lo[kr], P.pos_hi[kr], P.pos_th[kr], Hh);
       dd += P.pos_w[kr] * Hh * Hh;
       gg += P.pos_w[kr] * Hh * e;
+      ee += P.pos_w[kr] * e * e;
     }
     if (ar && P.flag_vel_limit) {
       const double e = hinge_limit(zz, -P.vel_lim[kr], P.vel_lim[kr], P.vel_th[kr], Hh);
       dd += P.vel_w[kr] * Hh * Hh;
       gg += P.vel_w[kr] * Hh * e;
+      ee += P.vel_w[kr] * e * e;
     }
     if (ar && kr == 1 && P.vdyn_w > 0.0) {
       dd += P.vdyn_w;
       gg += P.vdyn_w * zz;
+      ee += P.vdyn_w * zz * zz;
     }
-    if (on_diag) S.r[k] += dd;
+    if (on_diag) {
+      S.r[k] += dd;
+      err_acc += ee;
+    }
     if (on_rhs) {
       if (!ar) gg += si.pts[I][NG + kr];
       for (int jj = 0; jj < I; jj++) {
@@ -202,6 +215,8 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
       S.r[k] = -gg;
     }
   }
+  err_acc = wave_sum(err_acc);
+  if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
   if (!odd) {
     tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
   } else {
@@ -325,23 +340,20 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
   int* flags = reinterpret_cast<int*>(red + CR_WAVES);  // [0] decision, [1] not-spd
 
   G2_STAMP(0);
-  // ---- graph error at `cur` (all 16 waves), then the gpmp2::optimize control flow
-  {
-    const double* eb = pb.rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+  // ---- graph error at `cur`: fixed-order sum of the per-block partials written by k_assemble,
+  // then the gpmp2::optimize control flow
+  if (w == 0) {
     double acc = 0.0;
-    for (int p = tid; p < P.P; p += blockDim.x) acc += eb[p];
-    const double* gb = pb.gpu + ((size_t)b * (P.n + 1) + P.n) * P.Npad;
-    for (int i = 1 + tid; i <= N; i += blockDim.x) acc += gb[i];
+    for (int i = lane; i <= N; i += 64) acc += pb.epart[(size_t)b * P.Npad + i];
     acc = wave_sum(acc);
-    if (w == 0) acc += misc_error(P, pb, b, cur, lane);
-    if (lane == 0) red[w] = acc;
-    if (tid == 0) flags[1] = 0;
+    if (lane == 0) {
+      red[0] = acc;
+      flags[1] = 0;
+    }
   }
   __syncthreads();
   if (tid == 0) {
-    double tot = 0.0;
-    for (int k = 0; k < CR_WAVES; k++) tot += red[k];
-    const double new_err = 0.5 * tot;
+    const double new_err = red[0];
     int decision = 0;  // 0 iterate, 1 stop(result = cur), 2 stop(result = last)
     const int it = pb.iters[b];
     double* tr = pb.trace + (size_t)b * (P.max_iter + 1);
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
   if (tid == 0) {
     pb.last_err[b] = pb.cur_err[b];
     pb.iters[b] += 1;
-    atomicAdd(pb.n_active, 1);
+    atomicAdd(pb.n_active + pass, 1);
   }
 }
 

@@ -59,7 +59,8 @@ struct PlanBuffers {
   int* active;             // 1 while the trajectory is still iterating
   int* phase;              // optimizer-specific sub-state
   int* notspd;             // [B] set when a level-1 pivot (k_assemble) was not positive
-  int* n_active;           // [1] device counter
+  double* epart;           // [B][Npad] per-block share of the graph error (k_assemble)
+  int* n_active;           // [max_pass] trajectories that iterated in each pass
   unsigned long long* stamps;  // [B][64] s_memtime stamps (diagnostic builds only)
 };
 

@@ -171,6 +171,8 @@ int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const doubl
 __global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) {
   const PlanParams& P = *pp;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b == 0)
+    for (int k = 0; k < (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 2; k++) pb.n_active[k] = 0;
   if (b >= P.B) return;
   pb.iters[b] = 0;
   pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;

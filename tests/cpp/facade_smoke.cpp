@@ -1,0 +1,43 @@
+// Builds against include/gpmp2mi_planner.hpp with plain g++ (no HIP, no GTSAM) and links the
+// product library.  On a box without a GPU the planner call must throw (no silent fallback);
+// on a GPU box it optimises a tiny 2-link problem and prints the iteration count.
+#include <cmath>
+#include <cstdio>
+
+#include "gpmp2mi_planner.hpp"
+
+using namespace gpmp2mi;
+
+int main() {
+  try {
+    Arm arm(2, {1.0, 1.0}, {0.0, 0.0}, {0.0, 0.0}, Pose3::Translation(0.0, 0.0, 0.0));
+    BodySphereVector spheres;
+    for (int l = 0; l < 2; l++)
+      for (double x : {-0.75, -0.25}) spheres.emplace_back(l, 0.1, std::array<double, 3>{x, 0.0, 0.0});
+    ArmModel model(arm, spheres);
+    const int n = 60;
+    Vector field(n * n);  // distance to a disc of radius 0.4 at (1.2, 1.0); column-major (row = y, col = x)
+    for (int x = 0; x < n; x++)
+      for (int y = 0; y < n; y++)
+        field[x * n + y] = std::hypot(-3.0 + 0.1 * x - 1.2, -3.0 + 0.1 * y - 1.0) - 0.4;
+    PlanarSDF sdf({-3.0, -3.0}, 0.1, n, n, field);
+    TrajOptimizerSetting setting(2);
+    setting.set_total_step(10);
+    setting.set_total_time(2.0);
+    setting.set_obs_check_inter(2);
+    setting.set_cost_sigma(0.1);
+    setting.set_epsilon(0.2);
+    setting.setGaussNewton();
+    const Vector start{0.0, 0.0}, end{1.5, 0.5}, zero{0.0, 0.0};
+    const Trajectory init = initArmTrajStraightLine(start, end, 10);
+    int iters = 0;
+    double err = 0;
+    const Trajectory out = BatchTrajOptimize2DArm(model, sdf, start, zero, end, zero, init, setting, &iters, &err);
+    std::printf("OK iterations=%d final_error=%.6f x_5=(%.4f, %.4f) collision=%.4f\n", iters, err, out.x(5)[0],
+                out.x(5)[1], CollisionCost2DArm(model, sdf, out, setting));
+    return 0;
+  } catch (const std::exception& e) {
+    std::printf("EXCEPTION %s\n", e.what());
+    return 3;
+  }
+}
