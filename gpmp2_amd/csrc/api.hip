@@ -3,6 +3,7 @@
 // There is deliberately no CPU compute path in this file: every entry point launches kernels.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -217,6 +218,8 @@ struct gpmp2mi_plan {
   int* h_nactive = nullptr;  // pinned [2]
   hipEvent_t ev[2] = {nullptr, nullptr};
   KernelTimer timer;
+  bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
+  int n_active_len = 0;
   bool problem_set = false;
   bool optimized = false;
   size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
@@ -600,8 +603,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
   G2_CHECK(robot->h.base_dof == 0, GPMP2MI_ERR_UNSUPPORTED, "Pose2 (Lie) planners are not built yet");
-  G2_CHECK(s->opt_type == GPMP2MI_OPT_GAUSS_NEWTON, GPMP2MI_ERR_UNSUPPORTED,
-           "only GaussNewton is built on device so far");
+  G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
+           "unknown opt_type");
   G2_CHECK(s->cost_sigma > 0 && s->conf_prior_sigma > 0 && s->vel_prior_sigma > 0, GPMP2MI_ERR_INVALID,
            "sigmas must be positive");
   if (s->flag_vel_limit && s->vel_limits)
@@ -687,7 +690,6 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   std::memset(&pb, 0, sizeof(pb));
   const size_t tsz = p->tsz();
   G2_TRY(plan_alloc(p.get(), &pb.params, 1));
-  G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
   G2_TRY(plan_alloc(p.get(), &pb.start_conf, (size_t)B * D));
   G2_TRY(plan_alloc(p.get(), &pb.start_vel, (size_t)B * D));
   G2_TRY(plan_alloc(p.get(), &pb.end_conf, (size_t)B * D));
@@ -695,9 +697,14 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.cur, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.last, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.trial, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.init, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.result, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.delta, tsz));
-  G2_TRY(plan_alloc(p.get(), &pb.dx_u, tsz));
+  G2_TRY(plan_alloc(p.get(), &pb.gvec, (size_t)B * (P.N + 1) * 16));
+  G2_TRY(plan_alloc(p.get(), &pb.htiles, P.opt_type == GPMP2MI_OPT_DOGLEG ? (size_t)B * (P.N + 1) * 512 : 1));
+  G2_TRY(plan_alloc(p.get(), &pb.hgpart, (size_t)B * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
+  G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * (P.n + 1) * P.Npad));
@@ -716,8 +723,18 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.phase, B));
   G2_TRY(plan_alloc(p.get(), &pb.notspd, B));
   G2_TRY(plan_alloc(p.get(), &pb.epart, (size_t)B * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.n_active, (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 2));
+  {
+    const char* e = getenv("GPMP2MI_GENERIC_GN");
+    p->generic_gn = e && e[0] == '1';
+    const int cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
+    // passes: GN one per iteration (+1); LM up to ~5 lambda retries per iterate; Dogleg up to ~16 halvings
+    const int mult = P.opt_type == GPMP2MI_OPT_LM ? 6 : P.opt_type == GPMP2MI_OPT_DOGLEG ? 18 : 1;
+    p->n_active_len = cap * mult + 3;
+    P.max_pass = p->n_active_len;
+  }
+  G2_TRY(plan_alloc(p.get(), &pb.n_active, p->n_active_len));
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
+  G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
   G2_HIP(hipHostMalloc((void**)&p->h_nactive, 2 * sizeof(int), hipHostMallocDefault));
   G2_HIP(hipEventCreateWithFlags(&p->ev[0], hipEventDisableTiming));
   G2_HIP(hipEventCreateWithFlags(&p->ev[1], hipEventDisableTiming));
@@ -742,8 +759,7 @@ static int plan_set_problem(gpmp2mi_plan* p, const double* sc, const double* sv,
   G2_HIP(hipMemcpyAsync(p->pb.start_vel, sv, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.end_conf, ec, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.end_vel, ev, bd, kind, st));
-  // `trial` doubles as the pristine copy of the initial values so optimize() can be re-run
-  G2_HIP(hipMemcpyAsync(p->pb.trial, init, p->tsz() * sizeof(double), kind, st));
+  G2_HIP(hipMemcpyAsync(p->pb.init, init, p->tsz() * sizeof(double), kind, st));
   if (kind == hipMemcpyHostToDevice) G2_HIP(hipStreamSynchronize(st));
   p->problem_set = true;
   p->optimized = false;
@@ -765,28 +781,62 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   const PlanParams& P = p->hp;
   PlanBuffers& pb = p->pb;
   p->timer.reset();
-  G2_HIP(hipMemcpyAsync(pb.cur, pb.trial, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
+  G2_HIP(hipMemcpyAsync(pb.cur, pb.init, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
   G2_TRY(launch_plan_reset(P, pb, st));
-  const int max_pass = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 1;
-  // Software-pipelined driver: pass k+1 is enqueued before the host looks at the active count of
-  // pass k, so the GPU never waits for the host.  When pass k turns out to have finished every
-  // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
-  for (int pass = 0; pass < max_pass; pass++) {
-    const int slot = pass & 1;
+  const int iter_cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
+  if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn) {
+    // ---- Gauss-Newton fast path: 3 launches per pass, step control fused into the solve kernel.
+    // Software-pipelined driver: pass k+1 is enqueued before the host looks at the active count of
+    // pass k, so the GPU never waits for the host.  When pass k turns out to have finished every
+    // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
+    const int max_pass = iter_cap + 1;
+    for (int pass = 0; pass < max_pass; pass++) {
+      const int slot = pass & 1;
+      p->timer.begin("linearize", st);
+      G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, 0, pb.active, st));
+      p->timer.begin("assemble", st);
+      G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+      p->timer.begin("gn_step_cr", st);
+      G2_TRY(launch_gn_step_cr(P, pb, pass, st));
+      p->timer.close(st);
+      G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
+      G2_HIP(hipEventRecord(p->ev[slot], st));
+      if (pass >= 1) {
+        G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
+        if (p->h_nactive[slot ^ 1] == 0) break;
+      }
+    }
+  } else {
+    // ---- generic trial-step path (LM, Dogleg; GN when forced): per pass
+    //   assemble (+ g^T H g) -> solve + trial point -> linearize(trial) into the spare buffer -> decide
+    // LM may retry an iterate with a larger lambda, Dogleg with a smaller radius, hence the cap.
+    const int max_pass = p->n_active_len - 1;
     p->timer.begin("linearize", st);
-    G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
-    p->timer.end(st);
-    p->timer.begin("assemble", st);
-    G2_TRY(launch_assemble(P, pb, pb.cur, pb.rec, pb.gpu, pb.active, st));
-    p->timer.end(st);
-    p->timer.begin("gn_step_cr", st);
-    G2_TRY(launch_gn_step_cr(P, pb, pass, st));
+    G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, 0, pb.active, st));
+    p->timer.begin("decide", st);
+    G2_TRY(launch_decide(P, pb, 0, true, st));
     p->timer.close(st);
-    G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
-    G2_HIP(hipEventRecord(p->ev[slot], st));
-    if (pass >= 1) {
-      G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
-      if (p->h_nactive[slot ^ 1] == 0) break;
+    for (int pass = 1; pass < max_pass; pass++) {
+      const int slot = pass & 1;
+      p->timer.begin("assemble", st);
+      G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+      if (P.opt_type == GPMP2MI_OPT_DOGLEG) {
+        p->timer.begin("ghg", st);
+        G2_TRY(launch_ghg(P, pb, st));
+      }
+      p->timer.begin("solve_step", st);
+      G2_TRY(launch_solve_step(P, pb, st));
+      p->timer.begin("linearize", st);
+      G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.trial, 1, pb.active, st));
+      p->timer.begin("decide", st);
+      G2_TRY(launch_decide(P, pb, pass, false, st));
+      p->timer.close(st);
+      G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
+      G2_HIP(hipEventRecord(p->ev[slot], st));
+      if (pass >= 2) {
+        G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
+        if (p->h_nactive[slot ^ 1] == 0) break;
+      }
     }
   }
   G2_HIP(hipStreamSynchronize(st));
@@ -822,8 +872,8 @@ int gpmp2mi_plan_graph_error(gpmp2mi_plan* p, const double* traj, double* err) {
   DevBuf<double> dt, de;
   G2_TRY(dt.upload(traj, p->tsz()));
   G2_TRY(de.alloc(p->hp.B));
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, p->hp, p->pb, dt.p, p->pb.rec2, p->pb.gpu2, nullptr, nullptr));
-  G2_TRY(launch_error_reduce(p->hp, p->pb, dt.p, p->pb.rec2, p->pb.gpu2, de.p, nullptr));
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, p->hp, p->pb, dt.p, 1, nullptr, nullptr));
+  G2_TRY(launch_error_reduce(p->hp, p->pb, dt.p, 1, de.p, nullptr));
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(de.download(err));
   return GPMP2MI_OK;
@@ -840,13 +890,11 @@ int gpmp2mi_plan_linearize(gpmp2mi_plan* p, const double* traj, double* Hdiag, d
   if (Hoff) G2_TRY(dob.alloc((size_t)P.B * P.N * n * n));
   if (g) G2_TRY(dg.alloc(nb * n));
   if (err) G2_TRY(de.alloc(P.B));
-  // use the first record buffer's twin so an optimize() in flight is not disturbed
-  PlanBuffers pb = p->pb;
-  pb.rec = p->pb.rec2;
-  pb.gpu = p->pb.gpu2;
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, dt.p, pb.rec, pb.gpu, nullptr, nullptr));
-  G2_TRY(launch_export_normal_eq(P, pb, dt.p, dd.p, dob.p, dg.p, nullptr));
-  if (err) G2_TRY(launch_error_reduce(P, pb, dt.p, pb.rec, pb.gpu, de.p, nullptr));
+  // evaluate into the spare record buffer (the one that does not hold the linearization at `cur`)
+  const PlanBuffers& pb = p->pb;
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, dt.p, 1, nullptr, nullptr));
+  G2_TRY(launch_export_normal_eq(P, pb, dt.p, 1, dd.p, dob.p, dg.p, nullptr));
+  if (err) G2_TRY(launch_error_reduce(P, pb, dt.p, 1, de.p, nullptr));
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(dd.download(Hdiag));
   G2_TRY(dob.download(Hoff));

@@ -106,9 +106,7 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
 // =============================================================================== assemble
 template <int D>
 __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
-                                                  const double* __restrict__ traj,
-                                                  const double* __restrict__ rec,
-                                                  const double* __restrict__ gpu,
+                                                  const double* __restrict__ traj, int bufsel,
                                                   double* __restrict__ tiles,
                                                   const int* __restrict__ active) {
   constexpr int n = 2 * D, NG = D * (D + 1) / 2;
@@ -117,8 +115,12 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
   const int N = P.N, I = P.I;
   const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
   if (active && !active[b]) return;
+  // Dogleg retries (phase 1: same linearization, smaller trust region) need no new factorisation
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG && active && pb.phase[b] != 0) return;
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
   __shared__ typename Asm::Slot slots[2];
+  const double* rec = rec_of(pb, pb.which[b], bufsel);
+  const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
   as.stage(i, slots[0]);
   as.stage(i + 1, slots[1]);
@@ -217,6 +219,22 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
   }
   err_acc = wave_sum(err_acc);
   if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
+  // gradient g_i (the rhs column holds -g_i), kept for the step-control scalars of LM / Dogleg
+  if (c == RHSCOL) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pb.gvec[((size_t)b * (N + 1) + i) * 16 + g + 4 * k] = -S.r[k];
+  }
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG) {  // un-eliminated blocks for g^T H g (k_ghg)
+    double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * TILE_DBL;
+    tile_store(ht, S, lane);
+    tile_store(ht + TILE_DBL, Cr, lane);
+  }
+  if (P.opt_type == GPMP2MI_OPT_LM) {  // LM damping: sqrt(lambda) I prior rows on every variable
+    const double lam = pb.lambda[b];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (g + 4 * k == c && c < n) S.r[k] += lam;
+  }
   if (!odd) {
     tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
   } else {
@@ -234,12 +252,12 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
   }
 }
 
-int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
-                    const double* gpu, const int* active, hipStream_t st) {
+int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                    const int* active, hipStream_t st) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
-  case DD: k_assemble<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, rec, gpu, pb.tiles, active); break;
+  case DD: k_assemble<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active); break;
     G2_ASM_CASE(1) G2_ASM_CASE(2) G2_ASM_CASE(3) G2_ASM_CASE(4) G2_ASM_CASE(5) G2_ASM_CASE(6) G2_ASM_CASE(7)
 #undef G2_ASM_CASE
     default:
@@ -322,6 +340,90 @@ constexpr int CR_WAVES = G2_CR_WAVES;
 #define G2_STAMP(k) do {} while (0)
 #endif
 
+// Forward elimination (levels h >= 2; level 1 was done by k_assemble) of one trajectory's system.
+// All CR_WAVES wavefronts of the workgroup take part; returns false (per wavefront) on a bad pivot.
+template <int n>
+__device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, int tid) {
+  const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  // ---- forward: block cyclic reduction.  Level h = 1 (odd blocks) was done by k_assemble.
+  // Phase h >= 2: every block that is still active (multiple of h) absorbs the Schur complements
+  // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
+  // updated diagonal tile back (U tasks, done by the wavefronts that have no E task).
+  double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
+  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
+  bool ok = true;
+  int hfinal = 1;
+  while (hfinal <= N) hfinal <<= 1;
+  for (int h = 2; h <= hfinal; h <<= 1) {
+    const bool final = (h == hfinal);
+    const int hh = h >> 1;
+    const int countE = final ? 1 : ((N / h) + 1) / 2;
+    const int countU = final ? 0 : (N / (2 * h)) + 1;  // multiples of 2h in [0, N]
+    for (int idx = w; idx < countE + countU; idx += CR_WAVES) {
+      const bool elim = idx < countE;
+      const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
+      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
+      Tile Cl = tile_zero(), Cr = tile_zero();
+      const int jm = j - hh, jp = j + hh;
+      if (jm >= 0) {
+        const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
+        schur_sub<n>(S, Wr, lane);
+        if (elim && !final) {
+          const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
+          Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
+        }
+      }
+      if (jp <= N) {
+        const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
+        schur_sub<n>(S, Wl, lane);
+        if (elim && !final && j + h <= N) {
+          const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
+          Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
+        }
+      }
+      if (!elim) {
+        tile_store(tiles + (size_t)j * TILE_DBL, S, lane);
+        continue;
+      }
+      Tile V;
+#pragma unroll
+      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+      ok = tile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
+      double* f = fac + (size_t)j * 3 * TILE_DBL;
+      tile_store(f, Cl, lane);
+      tile_store(f + TILE_DBL, Cr, lane);
+      tile_store(f + 2 * TILE_DBL, V, lane);
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+
+// Back-substitution down the same tree; leaves x of every block in xs[(N+1)][16] (LDS).
+template <int n>
+__device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs) {
+  const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  int hfinal = 1;
+  while (hfinal <= N) hfinal <<= 1;
+  for (int h = hfinal; h >= 1; h >>= 1) {
+    const bool final = (h == hfinal);
+    const int count = final ? 1 : ((N / h) + 1) / 2;
+    for (int idx = w; idx < count; idx += CR_WAVES) {
+      const int j = final ? 0 : h * (2 * idx + 1);
+      const double* f = fac + (size_t)j * 3 * TILE_DBL;
+      const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
+      const int jl = j - h, jr = j + h;
+      const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
+      const double xr = (!final && jr <= N) ? xs[jr * 16 + c] : 0.0;
+      const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+      if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
+    }
+    __syncthreads();
+  }
+
+}
+
 template <int D>
 __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* __restrict__ pp,
                                                                PlanBuffers pb, int pass) {
@@ -393,60 +495,8 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
   }
 
   G2_STAMP(1);
-  // ---- forward: block cyclic reduction.  Level h = 1 (odd blocks) was done by k_assemble.
-  // Phase h >= 2: every block that is still active (multiple of h) absorbs the Schur complements
-  // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
-  // updated diagonal tile back (U tasks, done by the wavefronts that have no E task).
-  int stamp_k = 2;
-  double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
-  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
-  bool ok = true;
-  int hfinal = 1;
-  while (hfinal <= N) hfinal <<= 1;
-  for (int h = 2; h <= hfinal; h <<= 1) {
-    const bool final = (h == hfinal);
-    const int hh = h >> 1;
-    const int countE = final ? 1 : ((N / h) + 1) / 2;
-    const int countU = final ? 0 : (N / (2 * h)) + 1;  // multiples of 2h in [0, N]
-    for (int idx = w; idx < countE + countU; idx += CR_WAVES) {
-      const bool elim = idx < countE;
-      const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
-      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
-      Tile Cl = tile_zero(), Cr = tile_zero();
-      const int jm = j - hh, jp = j + hh;
-      if (jm >= 0) {
-        const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
-        schur_sub<n>(S, Wr, lane);
-        if (elim && !final) {
-          const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
-          Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
-        }
-      }
-      if (jp <= N) {
-        const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
-        schur_sub<n>(S, Wl, lane);
-        if (elim && !final && j + h <= N) {
-          const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
-          Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
-        }
-      }
-      if (!elim) {
-        tile_store(tiles + (size_t)j * TILE_DBL, S, lane);
-        continue;
-      }
-      Tile V;
-#pragma unroll
-      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
-      ok = tile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
-      double* f = fac + (size_t)j * 3 * TILE_DBL;
-      tile_store(f, Cl, lane);
-      tile_store(f + TILE_DBL, Cr, lane);
-      tile_store(f + 2 * TILE_DBL, V, lane);
-    }
-    __syncthreads();
-    G2_STAMP(stamp_k);
-    stamp_k++;
-  }
+  const bool ok = cr_forward<n>(pb, b, N, tid);
+  G2_STAMP(2);
   if ((!ok && lane == 0) || (tid == 0 && pb.notspd[b])) flags[1] = 1;
   __syncthreads();
   if (flags[1]) {
@@ -460,25 +510,8 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
     return;
   }
 
-  // ---- backward: same tree, top down
-  for (int h = hfinal; h >= 1; h >>= 1) {
-    const bool final = (h == hfinal);
-    const int count = final ? 1 : ((N / h) + 1) / 2;
-    for (int idx = w; idx < count; idx += CR_WAVES) {
-      const int j = final ? 0 : h * (2 * idx + 1);
-      const double* f = fac + (size_t)j * 3 * TILE_DBL;
-      const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
-      const int jl = j - h, jr = j + h;
-      const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
-      const double xr = (!final && jr <= N) ? xs[jr * 16 + c] : 0.0;
-      const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
-      if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
-    }
-    __syncthreads();
-    G2_STAMP(stamp_k);
-    stamp_k++;
-  }
-
+  cr_backward<n>(pb, b, N, tid, xs);
+  G2_STAMP(3);
   // ---- last = cur ; cur = retract(cur, delta)
   for (size_t k = tid; k < tsz; k += blockDim.x) {
     const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
@@ -486,7 +519,7 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
     last[k] = v;
     cur[k] = v + xs[i * 16 + rho];
   }
-  G2_STAMP(stamp_k);
+  G2_STAMP(4);
   if (tid == 0) {
     pb.last_err[b] = pb.cur_err[b];
     pb.iters[b] += 1;
@@ -514,6 +547,184 @@ int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hip
   return GPMP2MI_OK;
 }
 
+
+// =============================================================================== trial steps (LM / Dogleg)
+// block-wide deterministic sum; every thread returns the total
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int k = 0; k < CR_WAVES; k++) t += red[k];
+  return t;
+}
+
+// Solve the current linearization of every active trajectory (cyclic reduction, factors from
+// k_assemble) and form the trial point, without any accept / reject decision:
+//   LM     : delta = -(H + lambda I)^-1 g,  trial = cur + delta; scalars g.delta, |delta|^2
+//            (LevenbergMarquardtOptimizer::tryLambda up to the retract)
+//   Dogleg : dx_n = -H^-1 g, dx_u = -(g.g / g^T H g) g, dogleg point for the trust radius,
+//            trial = cur + dx_d, model decrease q(dx_d)  (DoglegOptimizerImpl::ComputeDoglegPoint /
+//            ComputeBlend); phase 1 (radius halved after a rejected step) re-blends without solving
+//   GN     : as LM with lambda = 0
+template <int D>
+__global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (!pb.active[b]) return;
+  const int N = P.N;
+  const size_t tsz = (size_t)(N + 1) * n;
+  const double* cur = pb.cur + b * tsz;
+  double* trial = pb.trial + b * tsz;
+  double* delta = pb.delta + b * tsz;
+  double* sc = pb.scal + (size_t)b * SC_COUNT;
+  const double* gv = pb.gvec + (size_t)b * (N + 1) * 16;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* xs = smem;
+  double* red = smem + (size_t)(N + 1) * 16;
+  int* flags = reinterpret_cast<int*>(red + CR_WAVES);
+  const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
+  const bool resolve = !(dogleg && pb.phase[b] != 0);
+  if (tid == 0) flags[1] = 0;
+  __syncthreads();
+  if (resolve) {
+    const bool ok = cr_forward<n>(pb, b, N, tid);
+    if ((!ok && (tid & 63) == 0) || (tid == 0 && pb.notspd[b])) flags[1] = 1;
+    __syncthreads();
+    if (flags[1]) {
+      if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
+      return;
+    }
+    cr_backward<n>(pb, b, N, tid, xs);
+    double gd = 0.0, dd = 0.0, gg = 0.0;
+    for (size_t k = tid; k < tsz; k += blockDim.x) {
+      const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+      const double x = xs[i * 16 + rho], gk = gv[i * 16 + rho];
+      delta[k] = x;
+      gd = fma(gk, x, gd);
+      dd = fma(x, x, dd);
+      gg = fma(gk, gk, gg);
+    }
+    gd = block_sum(gd, red, tid);
+    dd = block_sum(dd, red, tid);
+    gg = block_sum(gg, red, tid);
+    if (tid == 0) {
+      sc[SC_GD] = gd;
+      sc[SC_DD] = dd;
+      sc[SC_GG] = gg;
+      sc[SC_GN] = gd;
+      sc[SC_NN] = dd;
+    }
+    if (dogleg) {
+      double acc = 0.0;
+      for (int i = tid; i <= N; i += blockDim.x) acc += pb.hgpart[(size_t)b * P.Npad + i];
+      acc = block_sum(acc, red, tid);
+      if (tid == 0) sc[SC_GHG] = acc;
+    }
+    __syncthreads();
+  }
+  if (!dogleg) {
+    for (size_t k = tid; k < tsz; k += blockDim.x) trial[k] = cur[k] + delta[k];
+    return;
+  }
+  // ---- Powell dogleg point for trust radius pb.lambda[b]
+  const double Delta = pb.lambda[b];
+  const double gg = sc[SC_GG], gHg = sc[SC_GHG], gn = sc[SC_GN], nn = sc[SC_NN];
+  const double step = -gg / gHg;          // dx_u = step * g   (optimizeGradientSearch)
+  const double uu = step * step * gg, un = step * gn;
+  const double DeltaSq = Delta * Delta;
+  double cu, cn, q;                        // dx_d = cu * g + cn * dx_n
+  if (DeltaSq < uu) {
+    const double k = sqrt(DeltaSq / uu);
+    cu = k * step;
+    cn = 0.0;
+    q = cu * gg + 0.5 * cu * cu * gHg;
+  } else if (DeltaSq < nn) {
+    const double a = uu - 2. * un + nn, bq = 2. * (un - uu), cq = uu - Delta * Delta;
+    const double sq = sqrt(bq * bq - 4 * a * cq);
+    const double tau1 = (-bq + sq) / (2. * a), tau2 = (-bq - sq) / (2. * a);
+    const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
+    cu = (1. - tau) * step;
+    cn = tau;
+    // g^T x + 0.5 x^T H x with H dx_n = -g
+    q = cu * gg + cn * gn + 0.5 * (cu * cu * gHg - 2.0 * cu * cn * gg - cn * cn * gn);
+  } else {
+    cu = 0.0;
+    cn = 1.0;
+    q = 0.5 * gn;
+  }
+  double xn = 0.0;
+  for (size_t k = tid; k < tsz; k += blockDim.x) {
+    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+    const double x = cu * gv[i * 16 + rho] + cn * delta[k];
+    trial[k] = cur[k] + x;
+    xn = fma(x, x, xn);
+  }
+  xn = block_sum(xn, red, tid);
+  if (tid == 0) {
+    sc[SC_Q] = q;
+    sc[SC_XNORM] = sqrt(xn);
+  }
+}
+
+int launch_solve_step(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B), block(64 * CR_WAVES);
+  const size_t shmem = ((size_t)(hp.N + 1) * 16 + CR_WAVES + 2) * sizeof(double);
+  switch (hp.D) {
+#define G2_SS_CASE(DD) \
+  case DD: k_solve_step<DD><<<grid, block, shmem, st>>>(pb.params, pb); break;
+    G2_SS_CASE(1) G2_SS_CASE(2) G2_SS_CASE(3) G2_SS_CASE(4) G2_SS_CASE(5) G2_SS_CASE(6) G2_SS_CASE(7)
+#undef G2_SS_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// g^T H g, block by block: share_i = g_i^T D_i g_i + 2 g_i^T H_{i,i+1} g_{i+1} from the tiles saved by
+// k_assemble (Dogleg only).  One wavefront per (trajectory, block).
+template <int D>
+__global__ __launch_bounds__(64) void k_ghg(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  if (!pb.active[b] || pb.phase[b] != 0) return;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * TILE_DBL;
+  const Tile Dt = tile_load(ht, lane), Ht = tile_load(ht + TILE_DBL, lane);
+  const double* gv = pb.gvec + ((size_t)b * (N + 1) + i) * 16;
+  const double gi_c = (c < n) ? gv[c] : 0.0;
+  const double gn_c = (c < n && i < N) ? gv[16 + c] : 0.0;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int rho = g + 4 * k;
+    const double gi_r = (rho < n) ? gv[rho] : 0.0;
+    if (c < n) acc += gi_r * (Dt.r[k] * gi_c + 2.0 * Ht.r[k] * gn_c);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) pb.hgpart[(size_t)b * P.Npad + i] = acc;
+}
+
+int launch_ghg(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  switch (hp.D) {
+#define G2_GHG_CASE(DD) \
+  case DD: k_ghg<DD><<<grid, block, 0, st>>>(pb.params, pb); break;
+    G2_GHG_CASE(1) G2_GHG_CASE(2) G2_GHG_CASE(3) G2_GHG_CASE(4) G2_GHG_CASE(5) G2_GHG_CASE(6) G2_GHG_CASE(7)
+#undef G2_GHG_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
 
 // diagnostic: exercises the cross-lane helpers so tests can pin their lane semantics on hardware
 __global__ void k_debug_crosslane(const double* __restrict__ in, double* __restrict__ out) {

@@ -11,6 +11,7 @@ constexpr int TILE = 16;   // block-tridiagonal tile edge (n = 2*dof <= 16 in th
 // Uniform parameters of a plan; lives in HBM, read through scalar loads.
 struct PlanParams {
   int B, N, I, P, Ppad, D, n, NG, REC, Npad;
+  int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
@@ -38,6 +39,7 @@ struct PlanBuffers {
   double* cur;             // [B][N+1][2D]  opt->values()
   double* last;            // [B][N+1][2D]  last_values
   double* trial;           // [B][N+1][2D]  LM / Dogleg trial point
+  double* init;            // [B][N+1][2D]  pristine initial values (optimize() can be re-run)
   double* result;          // [B][N+1][2D]
   double* rec;             // [B][REC][Ppad] per-point G (packed upper), g, e   (buffer 0)
   double* rec2;            // second buffer for trial linearizations (LM / Dogleg)
@@ -46,7 +48,11 @@ struct PlanBuffers {
   double* tiles;           // [B][N+1][256] diagonal tile S_i = [D_i | -g_i] of every even block (updated in place)
   double* fac;             // [B][N+1][3][256] factor tiles Wl, Wr (both carry y), V = R^-T
   double* delta;           // [B][N+1][2D]
-  double* dx_u;            // Dogleg steepest-descent point
+  double* gvec;            // [B][N+1][16] gradient g_i = J^T Sigma^-1 r of the current linearization
+  double* htiles;          // [B][N+1][2][256] un-eliminated D_i and H_{i,i+1} (Dogleg: g^T H g)
+  double* hgpart;          // [B][Npad] per-block share of g^T H g
+  double* scal;            // [B][16] per-trajectory scalars of the current trial step (see SC_*)
+  int* which;              // [B] record buffer (0: rec/gpu, 1: rec2/gpu2) holding the linearization at `cur`
   // per-trajectory scalars
   double* cur_err;         // error at `cur`
   double* prev_err;        // currentError of gpmp2::optimize
@@ -64,17 +70,31 @@ struct PlanBuffers {
   unsigned long long* stamps;  // [B][64] s_memtime stamps (diagnostic builds only)
 };
 
+// scalars of a trial step (PlanBuffers::scal)
+enum { SC_GD = 0, SC_DD, SC_GG, SC_GHG, SC_GN, SC_NN, SC_Q, SC_XNORM, SC_ZERO_STEP, SC_COUNT = 16 };
+
+// record buffers of trajectory b: sel = 0 -> the linearization at `cur`, 1 -> the other one
+__host__ __device__ inline double* rec_of(const PlanBuffers& pb, int which_b, int sel) {
+  return (which_b ^ sel) ? pb.rec2 : pb.rec;
+}
+__host__ __device__ inline double* gpu_of(const PlanBuffers& pb, int which_b, int sel) {
+  return (which_b ^ sel) ? pb.gpu2 : pb.gpu;
+}
+
 int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
-                     const PlanParams& hp, const PlanBuffers& pb, const double* traj, double* rec,
-                     double* gpu, const int* active, hipStream_t st);
+                     const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                     const int* active, hipStream_t st);
 int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
-int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
-                    const double* gpu, const int* active, hipStream_t st);
+int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                    const int* active, hipStream_t st);
+int launch_solve_step(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_ghg(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st);
 int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
-int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
-                        const double* rec, const double* gpu, double* err, hipStream_t st);
-int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj,
+int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                        double* err, hipStream_t st);
+int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                             double* Hdiag, double* Hoff, double* g, hipStream_t st);
 int launch_block_tridiag_solve(int B, int nblk, int n, const double* Hd, const double* Ho,
                                const double* b, double* x, int* ok, double* scratch, hipStream_t st);

@@ -27,15 +27,16 @@ namespace g2 {
 template <int KIND, int AD, int SDIM>
 __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
                                                    const PlanParams* __restrict__ pp,
-                                                   const double* __restrict__ traj,
-                                                   double* __restrict__ rec, double* __restrict__ gpu,
-                                                   const int* __restrict__ active) {
+                                                   PlanBuffers pb, const double* __restrict__ traj,
+                                                   int bufsel, const int* __restrict__ active) {
   using K = Kin<KIND, AD>;
   constexpr int D = K::DOF, n = 2 * D, NG = D * (D + 1) / 2;
   const PlanParams& P = *pp;
   const int nchunk = P.Ppad / 64;
   const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
   if (active && !active[b]) return;
+  double* __restrict__ rec = rec_of(pb, pb.which[b], bufsel);
+  double* __restrict__ gpu = gpu_of(pb, pb.which[b], bufsel);
   __shared__ RobotDev R;
   stage_robot(&R, Rg);
   const int p = chunk * 64 + threadIdx.x;
@@ -136,32 +137,31 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
 }
 
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
-                     const PlanBuffers& pb, const double* traj, double* rec, double* gpu,
-                     const int* active, hipStream_t st) {
+                     const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
+                     hipStream_t st) {
   const dim3 grid(hp.B * (hp.Ppad / 64)), block(64);
   if (sdf.dim == 3) {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, traj, rec, gpu, active)));
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
   } else {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, traj, rec, gpu, active)));
+    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
 
 __global__ __launch_bounds__(64) void k_error_reduce(const PlanParams* __restrict__ pp, PlanBuffers pb,
-                                                      const double* __restrict__ traj,
-                                                      const double* __restrict__ rec,
-                                                      const double* __restrict__ gpu,
+                                                      const double* __restrict__ traj, int bufsel,
                                                       double* __restrict__ err) {
   const PlanParams& P = *pp;
   const int b = blockIdx.x, lane = threadIdx.x;
-  const double e = total_error(P, pb, b, traj + (size_t)b * (P.N + 1) * P.n, rec, gpu, lane);
+  const double e = total_error(P, pb, b, traj + (size_t)b * (P.N + 1) * P.n, rec_of(pb, pb.which[b], bufsel),
+                               gpu_of(pb, pb.which[b], bufsel), lane);
   if (lane == 0) err[b] = e;
 }
 
-int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, const double* rec,
-                        const double* gpu, double* err, hipStream_t st) {
-  k_error_reduce<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, traj, rec, gpu, err);
+int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                        double* err, hipStream_t st) {
+  k_error_reduce<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, traj, bufsel, err);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
@@ -172,12 +172,14 @@ __global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) 
   const PlanParams& P = *pp;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0)
-    for (int k = 0; k < (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter) + 2; k++) pb.n_active[k] = 0;
+    for (int k = 0; k < P.max_pass; k++) pb.n_active[k] = 0;
   if (b >= P.B) return;
   pb.iters[b] = 0;
   pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
   pb.active[b] = 1;
   pb.phase[b] = 0;
+  pb.which[b] = 0;
+  for (int k = 0; k < SC_COUNT; k++) pb.scal[(size_t)b * SC_COUNT + k] = 0.0;
   pb.notspd[b] = 0;
   pb.cur_err[b] = pb.prev_err[b] = pb.last_err[b] = pb.final_err[b] = 0.0;
   pb.lambda[b] = (P.opt_type == GPMP2MI_OPT_DOGLEG) ? P.dl_delta0 : P.lm_lambda0;
@@ -191,10 +193,157 @@ int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t s
   return GPMP2MI_OK;
 }
 
+// =============================================================================== step control
+// One wavefront per trajectory.  `init`: error of the initial values + the early exits of
+// gpmp2::optimize (planner/BatchTrajOptimizer.cpp:248-268).  Otherwise: the trial point produced by
+// k_solve_step has been linearized into the spare record buffer; compute its graph error and apply
+//   GaussNewtonOptimizer::iterate      (always accept)
+//   LevenbergMarquardtOptimizer::tryLambda  (model fidelity test, lambda *= / /= 10, give up at 1e5)
+//   DoglegOptimizerImpl::Iterate(ONE_STEP_PER_ITERATION)  (gain ratio rho, trust radius update)
+// followed by the do/while of gpmp2::optimize (checkConvergence, max_iter, no-increase rollback).
+// GTSAM semantics restated from upstream -- identical to oracle_core.cpp.
+__global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (!pb.active[b]) return;
+  const int N = P.N, n = P.n;
+  const size_t tsz = (size_t)(N + 1) * n;
+  double* cur = pb.cur + b * tsz;
+  double* last = pb.last + b * tsz;
+  double* trial = pb.trial + b * tsz;
+  double* result = pb.result + b * tsz;
+  double* sc = pb.scal + (size_t)b * SC_COUNT;
+  double* tr = pb.trace + (size_t)b * (P.max_iter + 1);
+  const int wh = pb.which[b];
+  // action: 0 keep iterating, 1 finish with cur, 2 finish with last; accept: copy trial -> cur
+  int action = 0, accept = 0;
+
+  if (init) {
+    const double err = total_error(P, pb, b, cur, rec_of(pb, wh, 0), gpu_of(pb, wh, 0), lane);
+    if (lane == 0) {
+      pb.cur_err[b] = pb.prev_err[b] = err;
+      tr[0] = err;
+      if (P.fixed_iters == 0 && err <= P.err_tol) { action = 1; pb.status[b] = GPMP2MI_TRAJ_ALREADY_OPTIMAL; }
+      else if (P.fixed_iters == 0 && P.max_iter <= 0) { action = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; }
+      if (action) pb.final_err[b] = err;
+    }
+  } else {
+    const bool failed = pb.notspd[b] != 0;
+    double new_err = 0.0;
+    if (!failed) new_err = total_error(P, pb, b, trial, rec_of(pb, wh, 1), gpu_of(pb, wh, 1), lane);
+    if (lane == 0) {
+      pb.notspd[b] = 0;
+      const double cur_err = pb.cur_err[b];
+      bool iterate_done = false;   // GTSAM iterate() returned
+      bool moved = false;          // ... with new values
+      double err_after = cur_err;
+      if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON) {
+        if (failed) { action = 1; pb.status[b] = GPMP2MI_TRAJ_NOT_SPD; pb.final_err[b] = cur_err; }
+        else { iterate_done = moved = true; err_after = new_err; }
+      } else if (P.opt_type == GPMP2MI_OPT_LM) {
+        double lambda = pb.lambda[b];
+        bool step_ok = false, stop = false;
+        if (!failed) {
+          const double old_lin = cur_err;
+          const double lin_change = -(0.5 * sc[SC_GD] - 0.5 * lambda * sc[SC_DD]);
+          if (lin_change >= 0) {
+            const double cost_change = cur_err - new_err;
+            if (lin_change > 2.220446049250313e-16 * old_lin) step_ok = (cost_change / lin_change) > P.lm_min_fidelity;
+            if (fabs(cost_change) < P.rel_thresh * cur_err) stop = true;
+          }
+        }
+        if (step_ok) {
+          iterate_done = moved = true;
+          err_after = new_err;
+          lambda = fmax(P.lm_lower, lambda / P.lm_factor);
+        } else if (!stop) {
+          lambda *= P.lm_factor;
+          if (lambda >= P.lm_upper) iterate_done = true;  // give up: state unchanged
+        } else {
+          iterate_done = true;                            // relative cost change tiny: state unchanged
+        }
+        pb.lambda[b] = lambda;
+      } else {  // Dogleg
+        if (failed) { action = 1; pb.status[b] = GPMP2MI_TRAJ_NOT_SPD; pb.final_err[b] = cur_err; }
+        else {
+          double Delta = pb.lambda[b];
+          const double f_error = cur_err, M_error = cur_err, new_M = M_error + sc[SC_Q];
+          const double rho = (fabs(f_error - new_err) < 1e-15 || fabs(M_error - new_M) < 1e-15)
+                                 ? 0.5 : (f_error - new_err) / (M_error - new_M);
+          if (rho >= 0.75) { Delta = fmax(Delta, 3.0 * sc[SC_XNORM]); iterate_done = moved = true; err_after = new_err; }
+          else if (rho >= 0.25) { iterate_done = moved = true; err_after = new_err; }
+          else if (rho >= 0.0) { if (Delta > 1e-5) Delta = 0.5 * Delta; iterate_done = moved = true; err_after = new_err; }
+          else if (Delta > 1e-5) { Delta *= 0.5; pb.phase[b] = 1; }           // retry, same linearization
+          else { iterate_done = true; err_after = cur_err; }                  // zero step
+          pb.lambda[b] = Delta;
+          if (iterate_done) pb.phase[b] = 0;
+        }
+      }
+      if (iterate_done) {
+        const bool counted = moved || P.opt_type == GPMP2MI_OPT_DOGLEG;  // LM give-up does not count
+        const int it = pb.iters[b] + (counted ? 1 : 0);
+        pb.iters[b] = it;
+        if (moved) accept = 1;
+        // trace = error after every call to iterate() (an LM call that gives up repeats the value);
+        // LM keeps its call counter in `phase`, which only Dogleg uses otherwise
+        const int call = (P.opt_type == GPMP2MI_OPT_LM) ? ++pb.phase[b] : it;
+        if (call <= P.max_iter) tr[call] = err_after;
+        const double prev = pb.prev_err[b];
+        if (P.fixed_iters > 0) {
+          if (it >= P.fixed_iters || !counted) { action = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; pb.final_err[b] = err_after; }
+        } else {
+          const bool conv = check_convergence(P.rel_thresh, P.abs_tol, P.err_tol, prev, err_after);
+          if (it < P.max_iter && !conv) {
+            pb.prev_err[b] = err_after;
+          } else if (err_after > prev && P.no_increase) {
+            action = 2;  // the values before this iterate
+            pb.status[b] = GPMP2MI_TRAJ_ROLLED_BACK;
+            pb.final_err[b] = prev;
+          } else {
+            action = 1;
+            pb.status[b] = conv ? GPMP2MI_TRAJ_CONVERGED : GPMP2MI_TRAJ_MAX_ITER;
+            pb.final_err[b] = err_after;
+          }
+        }
+        pb.cur_err[b] = err_after;
+      }
+    }
+  }
+  action = __shfl(action, 0, 64);
+  accept = __shfl(accept, 0, 64);
+  if (accept) {
+    if (action == 2) {
+      // rollback: the result is the pre-step `cur`; nothing else reads cur afterwards
+      for (size_t k = lane; k < tsz; k += 64) result[k] = cur[k];
+    } else {
+      for (size_t k = lane; k < tsz; k += 64) {
+        last[k] = cur[k];
+        cur[k] = trial[k];
+      }
+      if (lane == 0) pb.which[b] = wh ^ 1;  // the trial linearization is now the one at cur
+    }
+  }
+  if (action == 1) {
+    for (size_t k = lane; k < tsz; k += 64) result[k] = cur[k];
+  } else if (action == 2 && !accept) {
+    for (size_t k = lane; k < tsz; k += 64) result[k] = last[k];
+  }
+  if (lane == 0) {
+    if (action != 0) pb.active[b] = 0;
+    else atomicAdd(pb.n_active + pass, 1);
+  }
+}
+
+int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st) {
+  k_decide<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, pass, init ? 1 : 0);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 // =============================================================================== export H, g
 template <int D>
 __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __restrict__ pp, PlanBuffers pb,
-                                                          const double* __restrict__ traj,
+                                                          const double* __restrict__ traj, int bufsel,
                                                           double* __restrict__ Hd, double* __restrict__ Ho,
                                                           double* __restrict__ gout) {
   constexpr int n = 2 * D;
@@ -203,7 +352,7 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
   const int b = blockIdx.x, lane = threadIdx.x, c = lane & 15, g = lane >> 4, N = P.N;
   const double* tr = traj + (size_t)b * (N + 1) * n;
   __shared__ typename Asm::Slot slots[2];
-  Asm as(P, pb, pb.rec, pb.gpu, b, lane);
+  Asm as(P, pb, rec_of(pb, pb.which[b], bufsel), gpu_of(pb, pb.which[b], bufsel), b, lane);
   double pf[Asm::NROUND];
   as.prefetch(0, pf);
   as.commit(0, pf, slots[0]);
@@ -233,12 +382,12 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
   }
 }
 
-int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, double* Hd,
-                            double* Ho, double* g, hipStream_t st) {
+int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                            double* Hd, double* Ho, double* g, hipStream_t st) {
   const dim3 grid(hp.B), block(64);
   switch (hp.D) {
 #define G2_EXP_CASE(DD) \
-  case DD: k_export_normal_eq<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, Hd, Ho, g); break;
+  case DD: k_export_normal_eq<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g); break;
     G2_EXP_CASE(1) G2_EXP_CASE(2) G2_EXP_CASE(3) G2_EXP_CASE(4) G2_EXP_CASE(5) G2_EXP_CASE(6) G2_EXP_CASE(7)
 #undef G2_EXP_CASE
     default:

@@ -211,3 +211,55 @@ def test_crosslane_primitives(engine):
     np.testing.assert_array_equal(out[7].reshape(4, 16), np.repeat(rows[:, 13:14], 16, axis=1))
     np.testing.assert_allclose(out[5].reshape(4, 16), np.repeat(rows.sum(axis=1, keepdims=True), 16, axis=1), atol=1e-14)
     np.testing.assert_allclose(out[6].reshape(4, 16), np.tile(rows.sum(axis=0), (4, 1)), atol=1e-14)
+
+
+@pytest.mark.parametrize("opt", ["LM", "DOGLEG"])
+def test_lm_and_dogleg_match_oracle(engine, oracle, small_wam, opt):
+    """LevenbergMarquardt (lambda0 = 100) and Dogleg (delta0 = 0.2) step control on device vs the
+    oracle's restatement of GTSAM's semantics ('parity unpinned' w.r.t. GTSAM itself)."""
+    p = small_wam
+    st = problems.wam_setting(12, 3, opt)
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, st, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, st, *_args(p), p.init)
+    _compare_solves(res, ref, st.max_iter)
+    tr = res["error_trace"]
+    for b in range(p.B):      # accepted steps never increase the error
+        t = tr[b][~np.isnan(tr[b])]
+        assert np.all(np.diff(t) <= 1e-9 * t[0])
+
+
+def test_arm3_planner_config2_dogleg_with_limits(engine, oracle):
+    """BASELINE config 2: Arm3PlannerExample through BatchTrajOptimize2DArm rules -- Dogleg, planar
+    SDF, joint + velocity limits, I = 3."""
+    p = problems.arm3_planner()
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_generic_path_reproduces_fused_gauss_newton(engine, small_wam, monkeypatch):
+    """The trial-step machinery (assemble / solve_step / linearize / decide) run with GaussNewton must
+    give exactly what the fused fast path gives."""
+    p = small_wam
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    a = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    monkeypatch.setenv("GPMP2MI_GENERIC_GN", "1")
+    b = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    assert list(a["iters"]) == list(b["iters"]) and list(a["status"]) == list(b["status"])
+    np.testing.assert_allclose(a["traj"], b["traj"], atol=1e-9)
+    np.testing.assert_allclose(a["final_error"], b["final_error"], rtol=1e-10)
+
+
+def test_full_size_headline_config_lm(engine, oracle):
+    p = problems.wam_restarts(B=8, opt="LM")
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    sel = [0, 5]
+    ref = oracle.batch_optimize(ro, so, p.setting, p.start_conf[sel], p.start_vel[sel], p.end_conf[sel],
+                                p.end_vel[sel], p.init[sel], nthreads=2)
+    assert list(res["iters"][sel]) == list(ref["iters"])
+    np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
+    np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
