@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="restarts per GPU (BASELINE config 3: 64)")
     ap.add_argument("--opt", default="GN", choices=["GN", "LM", "DOGLEG"])
+    ap.add_argument("--workload", default="restarts", choices=["restarts", "windows"],
+                    help="restarts = BASELINE config 3 (default, the metric's config); windows = config 4 "
+                         "(receding-horizon windows warm-started from the solved trajectory, 3 fixed GN iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="restarts in the CPU sample (0 = auto)")
     return ap.parse_args()
@@ -65,6 +68,23 @@ def cpu_baseline(p, sample, threads):
                 seconds=dt, traj_iters_per_sec=float(np.sum(res["iters"] + 1)) / dt), res
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of `kernel_prefix` from the newest committed PMC summary under profiles/
+    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same
+    command, gfx950 correction applied; see profiles/README.md).  None when no summary matches."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, v in d.get("kernels", {}).items():
+            if name.startswith(kernel_prefix):
+                best = (v["hbm_bytes_per_launch_corrected"], os.path.basename(f))
+    return best
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,10 +101,19 @@ def main():
 
     from gpmp2_amd import engine, problems
 
+    from gpmp2_amd import sharding
+
     B = args.batch
-    p = problems.wam_restarts(B=B * world, opt=args.opt)     # weak scaling: B restarts per rank
-    lo, hi = rank * B, (rank + 1) * B
     eng = engine.Engine()
+    if args.workload == "restarts":
+        p = problems.wam_restarts(B=B * world, opt=args.opt)     # weak scaling: B restarts per rank
+    else:
+        base = problems.wam_restarts(B=1, opt="GN")
+        r0, s0 = eng.robot(base.model), eng.sdf(base.sdf_origin, base.sdf_cell, base.sdf_data)
+        sol = eng.batch_optimize(r0, s0, base.setting, base.start_conf, base.start_vel, base.end_conf,
+                                 base.end_vel, base.init)["traj"][0]
+        p = problems.wam_windows(sol, B=B * world)
+    lo, hi = sharding.shard_range(B * world, world, rank)
     r = eng.robot(p.model)
     s = eng.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
     plan = eng.plan(r, s, p.setting, B)
@@ -104,7 +133,7 @@ def main():
         if world > 1:     # final gather of the results: the only collective on the path
             eng._ck(eng.lib.gpmp2mi_plan_get_result_dev(plan.h.ptr, C.c_void_p(out_traj.data_ptr()), None, None,
                                                         None, C.c_void_p(stream)))
-            dist.all_gather_into_tensor(gathered, out_traj)
+            gathered[...] = sharding.gather_results(out_traj, B * world)
 
     def fence():
         if world > 1:
@@ -142,8 +171,11 @@ def main():
             avg_ms = kern[dom]["ms"] / kern[dom]["launches"]
             units_per_launch = passes / launches_per_step      # trajectory-iterations per launch
             achieved = ALGO_BYTES_PER_TRAJ_ITER * units_per_launch / (avg_ms * 1e-3) / 1e9
+            tr = pmc_traffic("k_" + dom) if (args.workload == "restarts" and B == 64 and args.opt == "GN") else None
             roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        frac=achieved / HBM_PEAK_GBS, traffic=(tr[0] if tr else None),
+                        traffic_source=(tr[1] if tr else None),
+                        algorithmic_bytes_per_launch=ALGO_BYTES_PER_TRAJ_ITER * units_per_launch,
                         avg_launch_ms=avg_ms, launches_per_step=launches_per_step,
                         units_per_launch=units_per_launch,
                         kernels={k: dict(avg_ms=v["ms"] / v["launches"], launches_per_step=v["launches"] / args.steps)
@@ -151,8 +183,11 @@ def main():
         out = dict(metric="trajectories/sec", value=total_traj / dt, unit="trajectories/sec", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-                   config=dict(workload="WAMFactorGraphExample: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 SDF "
-                                        f"(Synth200), {B} random-init restarts per GPU, {args.opt} to tolerance",
+                   config=dict(workload=("WAMFactorGraphExample: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 SDF "
+                                         f"(Synth200), {B} random-init restarts per GPU, {args.opt} to tolerance")
+                               if args.workload == "restarts" else
+                               ("WAMReplannerExample receding horizon: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 SDF, "
+                                f"{B} warm-started windows per GPU, 3 fixed GN iterations"),
                                restarts_per_gpu=B, total_step=N, obs_check_inter=p.setting.obs_check_inter,
                                optimizer=args.opt, parallelism=f"trajectory-sharded x{world}"),
                    gn_iters_to_tol=dict(min=int(iters.min()), median=float(np.median(iters)), max=int(iters.max())),
@@ -162,6 +197,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(os.cpu_count() or 1, 64))
             sample = args.cpu_sample or min(B, max(8, threads))
+            sample = min(sample, 256)
             cb, ref = cpu_baseline(p, sample, threads)
             # parity gate before the timing counts: same iteration counts as the oracle on the sample
             cb["iters_match_gpu"] = bool(np.array_equal(ref["iters"], iters[:sample]))
