@@ -602,7 +602,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
-  G2_CHECK(robot->h.base_dof == 0, GPMP2MI_ERR_UNSUPPORTED, "Pose2 (Lie) planners are not built yet");
+  G2_CHECK(robot->h.base_dof == 0 || s->obs_check_inter == 0, GPMP2MI_ERR_UNSUPPORTED,
+           "Pose2 robots: GP-interpolated obstacle factors (obs_check_inter > 0) are not built yet");
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
            "unknown opt_type");
   G2_CHECK(s->cost_sigma > 0 && s->conf_prior_sigma > 0 && s->vel_prior_sigma > 0, GPMP2MI_ERR_INVALID,
@@ -627,6 +628,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.NG = D * (D + 1) / 2;
   P.REC = P.NG + D + 1;
   P.Npad = (P.N + 1 + 63) / 64 * 64;
+  P.lie = robot->h.base_dof == 3 ? 1 : 0;
+  P.GPREC = P.n + 1 + (P.lie ? 18 : 0);
   P.obs_skip_first = o.obs_skip_first_state;
   P.flag_pos_limit = s->flag_pos_limit;
   P.flag_vel_limit = s->flag_vel_limit;
@@ -634,7 +637,6 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.max_iter = s->max_iter;
   P.no_increase = s->final_iter_no_increase;
   P.fixed_iters = o.fixed_iterations;
-  P.lie = 0;
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
   // planner/BatchTrajOptimizer-inl.h:30-31
@@ -707,8 +709,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
-  G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * (P.n + 1) * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * (P.n + 1) * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * P.GPREC * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * P.GPREC * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256));
   G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));

@@ -1,4 +1,11 @@
-// assembler.h -- builds block-tridiagonal tiles from the per-point records of k_linearize.
+// assembler.h -- builds the block-tridiagonal tiles of one support state from the per-point records
+// of k_linearize.  Used by k_assemble (solver input) and k_export_normal_eq (parity tests).
+//
+// Vector-space robots: Kronecker structure -- a point with interpolation
+// scalars c contributes (c c^T) (x) G to the 2x2-block window and c (x) g to the gradient, and the
+// GP prior Hessian blocks are constants.  Pose2 robots (Lie path, config 5): the GP prior Jacobians
+// depend on the states (gp/GaussianProcessPriorLie.h:61-86); k_linearize stores the two 3x3 pose
+// blocks J1 = Hlog*Hcomp1*Hinv, J3 = Hlog per interval and the blocks are formed here.
 #pragma once
 #include "device_math.h"
 #include "plan.h"
@@ -6,21 +13,18 @@
 
 namespace g2 {
 
-// =============================================================================== assembly
-// Builds, for block i of trajectory b, the diagonal tile D_i, the coupling tile
-// [H_{i,i+1} | -g_i] and (optionally) nothing else, from the point records staged in LDS.
-// Kronecker structure: a point with interpolation scalars c contributes
-// (c c^T) (x) G to the 2x2-block window and c (x) g to the gradient.
+constexpr int GP_EXTRA_LIE = 18;  // J1 (9) + J3 (9) appended to the GP record of Pose2 robots
+
 template <int D>
 struct Assembler {
   static constexpr int n = 2 * D, NG = D * (D + 1) / 2, RECP = NG + D + 1;  // per-point record
-  static constexpr int NROUND = (RECP * (MAXI + 1) + n + 1 + 63) / 64;
+  static constexpr int GPN = n + 1 + GP_EXTRA_LIE;
 
   // LDS image of one interval: pts[jj][RECP] for jj = 0..I (I = unary of the end state), then
-  // the GP vector u (n) and energy
+  // the GP record: u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)]
   struct Slot {
     double pts[MAXI + 1][RECP];
-    double gp[n + 1];
+    double gp[GPN];
   };
 
   const PlanParams& P;
@@ -32,7 +36,6 @@ struct Assembler {
   int tri[4];
   bool valid[4];   // rho < n && c < n
   int a_row[4], k_row[4], a_col, k_col;
-  double KA[4], KB[4], KO[4], KOt[4];
 
   __device__ Assembler(const PlanParams& P_, const PlanBuffers& pb_, const double* rec_, const double* gpu_,
                        int b_, int lane_)
@@ -47,24 +50,20 @@ struct Assembler {
       k_row[k] = rho - a_row[k] * D;
       const int lo = min(k_row[k], k_col), hi = max(k_row[k], k_col);
       tri[k] = valid[k] ? lo * D - (lo * (lo - 1)) / 2 + (hi - lo) : 0;
-      KA[k] = valid[k] ? P.KA[rho * n + c] : 0.0;
-      KB[k] = valid[k] ? P.KB[rho * n + c] : 0.0;
-      KO[k] = valid[k] ? P.KO[rho * n + c] : 0.0;
-      KOt[k] = valid[k] ? P.KO[c * n + rho] : 0.0;
     }
   }
 
-  // global -> LDS for interval `iv` in one go (no software pipelining; used by k_assemble where
-  // every wavefront handles a single block).  Intervals beyond N read as zeros.
+  // global -> LDS for interval `iv` (0 = only the unary point of state 0).  Intervals beyond N read
+  // as zeros.
   __device__ __forceinline__ void stage(int iv, Slot& s) const {
     const int I = P.I;
     const int npt = (iv == 0) ? 1 : I + 1;
     const int nv = RECP * npt;
     const int p0 = (iv == 0) ? 0 : 1 + (iv - 1) * (I + 1);
     const double* rb = rec + (size_t)b * P.REC * P.Ppad;
-    const double* gb = gpu + (size_t)b * (n + 1) * P.Npad;
+    const double* gb = gpu + (size_t)b * P.GPREC * P.Npad;
     const bool in_range = iv <= P.N;
-    for (int v = lane; v < nv + n + 1; v += 64) {
+    for (int v = lane; v < nv + P.GPREC; v += 64) {
       if (v < nv) {
         const int k = v / npt, jj = v - k * npt;
         s.pts[(iv == 0) ? I : jj][k] = in_range ? rb[(size_t)k * P.Ppad + p0 + jj] : 0.0;
@@ -74,124 +73,160 @@ struct Assembler {
     }
   }
 
-  // global -> registers for interval `iv` (1..N); interval 0 is just the unary point of state 0
-  __device__ __forceinline__ void prefetch(int iv, double (&pf)[NROUND]) const {
-    const int I = P.I;
-    const int npt = (iv == 0) ? 1 : I + 1;
-    const int nv = RECP * npt;
-    const int p0 = (iv == 0) ? 0 : 1 + (iv - 1) * (I + 1);
-    const double* rb = rec + (size_t)b * P.REC * P.Ppad;
-    const double* gb = gpu + (size_t)b * (n + 1) * P.Npad;
-#pragma unroll
-    for (int m = 0; m < NROUND; m++) {
-      const int v = lane + 64 * m;
-      double x = 0.0;
-      if (iv <= P.N) {
-        if (v < nv) {
-          const int k = v / npt, jj = v - k * npt;
-          x = rb[(size_t)k * P.Ppad + p0 + jj];
-        } else if (iv > 0 && v < nv + n + 1) {
-          x = gb[(size_t)(v - nv) * P.Npad + iv];
-        }
-      }
-      pf[m] = x;
-    }
-  }
-
-  __device__ __forceinline__ void commit(int iv, const double (&pf)[NROUND], Slot& s) const {
-    const int I = P.I;
-    const int npt = (iv == 0) ? 1 : I + 1;
-    const int nv = RECP * npt;
-#pragma unroll
-    for (int m = 0; m < NROUND; m++) {
-      const int v = lane + 64 * m;
-      if (v < nv) {
-        const int k = v / npt, jj = v - k * npt;
-        s.pts[(iv == 0) ? I : jj][k] = pf[m];
-      } else if (v < nv + n + 1) {
-        s.gp[v - nv] = pf[m];
+  // sum_{a,b} L[a][kr] Qc^-1[a][b] R[b][kc] where L / R are either the identity (ML == nullptr) or
+  // the DxD block-diagonal Jacobian diag(M (3x3, row-major), sign * I)
+  __device__ __forceinline__ double lie_quad(const double* ML, double sL, const double* MR, double sR, int kr,
+                                             int kc) const {
+    double acc = 0.0;
+    const int a0 = (ML && kr < 3) ? 0 : kr, a1 = (ML && kr < 3) ? 3 : kr + 1;
+    const int b0 = (MR && kc < 3) ? 0 : kc, b1 = (MR && kc < 3) ? 3 : kc + 1;
+    for (int a = a0; a < a1; a++) {
+      const double la = !ML ? 1.0 : (kr < 3 ? ML[a * 3 + kr] : sL);
+      for (int bb = b0; bb < b1; bb++) {
+        const double rb_ = !MR ? 1.0 : (kc < 3 ? MR[bb * 3 + kc] : sR);
+        acc = fma(la * rb_, P.Qc_inv[a * D + bb], acc);
       }
     }
+    return acc;
   }
 
-  // si = slot of interval i (its unary point is state i), sn = slot of interval i+1.
-  // zi[k] = z_i[rho_k] (state value of this lane's rows).  Outputs the two tiles.
-  __device__ __forceinline__ void build(int i, const Slot& si, const Slot& sn, const double (&zi)[4],
-                                        Tile& Dt, Tile& Wt) const {
+  // Tiles of block i: S = [D_i | -g_i in column RHSCOL], Cl = H_{i,i-1}, Cr = H_{i,i+1}; returns this
+  // lane's share of the block's graph-error contribution (to be wave-summed; not yet halved).
+  // si = slot of interval i (its unary point is state i), sn = slot of interval i+1; z = state i.
+  __device__ __forceinline__ double build_tiles(int i, const Slot& si, const Slot& sn, const double* z, Tile& S,
+                                                Tile& Cl, Tile& Cr) const {
     const int I = P.I, N = P.N;
-    const bool has_prev = i > 0, has_next = i < N;
+    const bool has_prev = i > 0, has_next = i < N, lie = P.lie != 0;
+    const double dt = P.delta_t, w0 = P.Winv[0], w1 = P.Winv[1], w3 = P.Winv[3];
+    const double* J3i = si.gp + n + 1 + 9;   // of interval i   (state i is the second state)
+    const double* J1n = sn.gp + n + 1;       // of interval i+1 (state i is the first state)
+    const double* J1i = si.gp + n + 1;
+    const double* J3n = sn.gp + n + 1 + 9;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      double d = 0.0, h = 0.0;
+      double d = 0.0, hr = 0.0, hl = 0.0;
       if (valid[k]) {
-        const int ar = a_row[k], ac = a_col, t = tri[k];
-        d = (has_prev ? KB[k] : 0.0) + (has_next ? KA[k] : 0.0);
-        h = has_next ? KO[k] : 0.0;
+        const int ar = a_row[k], ac = a_col, t = tri[k], kr = k_row[k], kc = k_col, rho = g + 4 * k;
+        if (!lie) {
+          // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
+          // KO = -Phi^T Q^-1 = H_{i,i+1}
+          d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
+          hr = has_next ? P.KO[rho * n + c] : 0.0;
+          hl = has_prev ? P.KO[c * n + rho] : 0.0;
+        } else {
+          // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
+          const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
+          if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
+            const double* L = ar ? nullptr : J3i;
+            d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
+            hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
+          }
+          if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
+            const double* L = ar ? nullptr : J1n;
+            d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
+            hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
+          }
+        }
         if (!ar && !ac) d += si.pts[I][t];  // unary obstacle factor at state i
         for (int jj = 0; jj < I; jj++) {
           const GpCoef cf = P.coef[jj];
+          const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
+          const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
           if (has_prev) {
-            const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
-            d = fma(w2r * w2c, si.pts[jj][t], d);
+            const double Gp = si.pts[jj][t];
+            d = fma(w2r * w2c, Gp, d);
+            hl = fma(w2r * w1c, Gp, hl);  // rows: state i (second), cols: state i-1 (first)
           }
           if (has_next) {
-            const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
-            const double w2c = ac ? cf.p12 : cf.p11;
             const double Gn = sn.pts[jj][t];
             d = fma(w1r * w1c, Gn, d);
-            h = fma(w1r * w2c, Gn, h);
+            hr = fma(w1r * w2c, Gn, hr);  // rows: state i (first), cols: state i+1 (second)
           }
         }
       }
-      Dt.r[k] = d;
-      Wt.r[k] = h;
+      S.r[k] = d;
+      Cr.r[k] = hr;
+      Cl.r[k] = hl;
     }
-    // diagonal terms and the gradient column
+    // this block's share of the graph error: unary point of state i, the interpolated points and the
+    // GP prior of the interval ending at i, plus (below) the prior / limit / dynamics terms of state i
+    double err_acc = 0.0;
+    if (lane <= I && (lane == I || has_prev)) err_acc = si.pts[lane][NG + D];
+    if (lane == 63 && has_prev) err_acc += si.gp[n];
+    // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int rho = g + 4 * k;
       if (rho >= n) continue;
-      const int ar = a_row[k], kr = k_row[k];
       const bool on_diag = (c == rho), on_rhs = (c == RHSCOL);
       if (!on_diag && !on_rhs) continue;
-      double dd = 0.0, gg = 0.0;
-      const double z = zi[k];
-      if (i == 0 || i == N) {
+      const int ar = a_row[k], kr = k_row[k];
+      double dd = 0.0, gg = 0.0, ee = 0.0;
+      const double zz = z[rho];
+      if (i == 0 || i == N) {  // PriorFactor on x_0, v_0, x_N, v_N  (BatchTrajOptimizer-inl.h:41-48)
         const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
+        tg += (size_t)b * D;
         const double w = ar ? P.vel_prior_w : P.conf_prior_w;
+        double dz = zz - tg[kr];
+        if (lie && !ar && kr < 3) {
+          // gtsam 4.0 PriorFactor<Pose2Vector>: error = -Local(x, prior), H = I (see oracle_core.cpp)
+          const P2 bt = pose2_between(P2{z[0], z[1], z[2]}, P2{tg[0], tg[1], tg[2]});
+          dz = -(kr == 0 ? bt.x : kr == 1 ? bt.y : bt.th);
+        }
         dd += w;
-        gg += w * (z - tg[(size_t)b * D + kr]);
+        gg += w * dz;
+        ee += w * dz * dz;
       }
       double Hh;
-      if (!ar && P.flag_pos_limit) {
-        const double e = hinge_limit(z, P.pos_lo[kr], P.pos_hi[kr], P.pos_th[kr], Hh);
+      if (!ar && P.flag_pos_limit && !(lie && kr < 3)) {  // JointLimitFactorPose2Vector skips the base
+        const double e = hinge_limit(zz, P.pos_lo[kr], P.pos_hi[kr], P.pos_th[kr], Hh);
         dd += P.pos_w[kr] * Hh * Hh;
         gg += P.pos_w[kr] * Hh * e;
+        ee += P.pos_w[kr] * e * e;
       }
       if (ar && P.flag_vel_limit) {
-        const double e = hinge_limit(z, -P.vel_lim[kr], P.vel_lim[kr], P.vel_th[kr], Hh);
+        const double e = hinge_limit(zz, -P.vel_lim[kr], P.vel_lim[kr], P.vel_th[kr], Hh);
         dd += P.vel_w[kr] * Hh * Hh;
         gg += P.vel_w[kr] * Hh * e;
+        ee += P.vel_w[kr] * e * e;
       }
-      if (ar && kr == 1 && P.vdyn_w > 0.0) {
+      if (ar && kr == 1 && P.vdyn_w > 0.0) {  // VehicleDynamicsFactorPose2Vector: r = v(1)
         dd += P.vdyn_w;
-        gg += P.vdyn_w * z;
+        gg += P.vdyn_w * zz;
+        ee += P.vdyn_w * zz * zz;
       }
-      if (on_diag) Dt.r[k] += dd;
+      if (on_diag) {
+        S.r[k] += dd;
+        err_acc += ee;
+      }
       if (on_rhs) {
-        // obstacle gradients
         if (!ar) gg += si.pts[I][NG + kr];
         for (int jj = 0; jj < I; jj++) {
           const GpCoef cf = P.coef[jj];
           if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pts[jj][NG + kr], gg);
           if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pts[jj][NG + kr], gg);
         }
-        // GP prior gradient: + Phi^T u_{i+1} - u_i
-        if (has_next) gg += ar ? (P.delta_t * sn.gp[kr] + sn.gp[D + kr]) : sn.gp[kr];
-        if (has_prev) gg -= si.gp[rho];
-        Wt.r[k] = -gg;
+        if (!lie) {
+          // GP prior gradient: + Phi^T u_{i+1} - u_i
+          if (has_next) gg += ar ? (dt * sn.gp[kr] + sn.gp[D + kr]) : sn.gp[kr];
+          if (has_prev) gg -= si.gp[rho];
+        } else {
+          // + A_{i+1}^T u_{i+1} + Bm_i^T u_i
+          if (has_next) {
+            if (ar) gg += -dt * sn.gp[kr] - sn.gp[D + kr];
+            else if (kr < 3) gg += J1n[0 * 3 + kr] * sn.gp[0] + J1n[1 * 3 + kr] * sn.gp[1] + J1n[2 * 3 + kr] * sn.gp[2];
+            else gg -= sn.gp[kr];
+          }
+          if (has_prev) {
+            if (ar) gg += si.gp[D + kr];
+            else if (kr < 3) gg += J3i[0 * 3 + kr] * si.gp[0] + J3i[1 * 3 + kr] * si.gp[1] + J3i[2 * 3 + kr] * si.gp[2];
+            else gg += si.gp[kr];
+          }
+        }
+        S.r[k] = -gg;
       }
     }
+    return err_acc;
   }
 };
 

@@ -109,10 +109,10 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
                                                   const double* __restrict__ traj, int bufsel,
                                                   double* __restrict__ tiles,
                                                   const int* __restrict__ active) {
-  constexpr int n = 2 * D, NG = D * (D + 1) / 2;
+  constexpr int n = 2 * D;
   using Asm = Assembler<D>;
   const PlanParams& P = *pp;
-  const int N = P.N, I = P.I;
+  const int N = P.N;
   const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
   if (active && !active[b]) return;
   // Dogleg retries (phase 1: same linearization, smaller trust region) need no new factorisation
@@ -125,98 +125,9 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
   as.stage(i, slots[0]);
   as.stage(i + 1, slots[1]);
   __syncthreads();
-  const typename Asm::Slot& si = slots[0];
-  const typename Asm::Slot& sn = slots[1];
-  const bool has_prev = i > 0, has_next = i < N, odd = (i & 1) != 0;
-  const double* z = traj + ((size_t)b * (N + 1) + i) * n;
-
+  const bool odd = (i & 1) != 0;
   Tile S, Cl, Cr;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    double d = 0.0, hr = 0.0, hl = 0.0;
-    if (as.valid[k]) {
-      const int ar = as.a_row[k], ac = as.a_col, t = as.tri[k];
-      d = (has_prev ? as.KB[k] : 0.0) + (has_next ? as.KA[k] : 0.0);
-      hr = has_next ? as.KO[k] : 0.0;   // H_{i,i+1}[rho][c] = KO[rho][c]
-      hl = has_prev ? as.KOt[k] : 0.0;  // H_{i,i-1}[rho][c] = KO[c][rho]
-      if (!ar && !ac) d += si.pts[I][t];
-      for (int jj = 0; jj < I; jj++) {
-        const GpCoef cf = P.coef[jj];
-        const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
-        const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
-        if (has_prev) {
-          const double Gp = si.pts[jj][t];
-          d = fma(w2r * w2c, Gp, d);
-          hl = fma(w2r * w1c, Gp, hl);  // rows: state i (second), cols: state i-1 (first)
-        }
-        if (has_next) {
-          const double Gn = sn.pts[jj][t];
-          d = fma(w1r * w1c, Gn, d);
-          hr = fma(w1r * w2c, Gn, hr);  // rows: state i (first), cols: state i+1 (second)
-        }
-      }
-    }
-    S.r[k] = d;
-    Cr.r[k] = hr;
-    Cl.r[k] = hl;
-  }
-  // this block's share of the graph error: unary point of state i, the interpolated points and the
-  // GP prior of the interval ending at i, plus (below) the prior / limit / dynamics terms of state i
-  double err_acc = 0.0;
-  if (lane <= I && (lane == I || has_prev)) err_acc = si.pts[lane][NG + D];
-  if (lane == 63 && has_prev) err_acc += si.gp[n];
-  // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int rho = g + 4 * k;
-    if (rho >= n) continue;
-    const bool on_diag = (c == rho), on_rhs = (c == RHSCOL);
-    if (!on_diag && !on_rhs) continue;
-    const int ar = as.a_row[k], kr = as.k_row[k];
-    double dd = 0.0, gg = 0.0, ee = 0.0;
-    const double zz = z[rho];
-    if (i == 0 || i == N) {
-      const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
-      const double w = ar ? P.vel_prior_w : P.conf_prior_w;
-      const double dz = zz - tg[(size_t)b * D + kr];
-      dd += w;
-      gg += w * dz;
-      ee += w * dz * dz;
-    }
-    double Hh;
-    if (!ar && P.flag_pos_limit) {
-      const double e = hinge_limit(zz, P.pos_lo[kr], P.pos_hi[kr], P.pos_th[kr], Hh);
-      dd += P.pos_w[kr] * Hh * Hh;
-      gg += P.pos_w[kr] * Hh * e;
-      ee += P.pos_w[kr] * e * e;
-    }
-    if (ar && P.flag_vel_limit) {
-      const double e = hinge_limit(zz, -P.vel_lim[kr], P.vel_lim[kr], P.vel_th[kr], Hh);
-      dd += P.vel_w[kr] * Hh * Hh;
-      gg += P.vel_w[kr] * Hh * e;
-      ee += P.vel_w[kr] * e * e;
-    }
-    if (ar && kr == 1 && P.vdyn_w > 0.0) {
-      dd += P.vdyn_w;
-      gg += P.vdyn_w * zz;
-      ee += P.vdyn_w * zz * zz;
-    }
-    if (on_diag) {
-      S.r[k] += dd;
-      err_acc += ee;
-    }
-    if (on_rhs) {
-      if (!ar) gg += si.pts[I][NG + kr];
-      for (int jj = 0; jj < I; jj++) {
-        const GpCoef cf = P.coef[jj];
-        if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pts[jj][NG + kr], gg);
-        if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pts[jj][NG + kr], gg);
-      }
-      if (has_next) gg += ar ? (P.delta_t * sn.gp[kr] + sn.gp[D + kr]) : sn.gp[kr];
-      if (has_prev) gg -= si.gp[rho];
-      S.r[k] = -gg;
-    }
-  }
+  double err_acc = as.build_tiles(i, slots[0], slots[1], traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr);
   err_acc = wave_sum(err_acc);
   if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
   // gradient g_i (the rhs column holds -g_i), kept for the step-control scalars of LM / Dogleg
@@ -512,12 +423,14 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
 
   cr_backward<n>(pb, b, N, tid, xs);
   G2_STAMP(3);
-  // ---- last = cur ; cur = retract(cur, delta)
+  // ---- last = cur ; cur = retract(cur, delta)   (Values::retract; Pose2 chart for mobile bases)
+  for (size_t k = tid; k < tsz; k += blockDim.x) last[k] = cur[k];
+  __syncthreads();
   for (size_t k = tid; k < tsz; k += blockDim.x) {
     const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
-    const double v = cur[k];
-    last[k] = v;
-    cur[k] = v + xs[i * 16 + rho];
+    const double* zs = last + (size_t)i * n;
+    const double* dz = xs + i * 16;
+    cur[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
   }
   G2_STAMP(4);
   if (tid == 0) {
@@ -626,7 +539,12 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* 
     __syncthreads();
   }
   if (!dogleg) {
-    for (size_t k = tid; k < tsz; k += blockDim.x) trial[k] = cur[k] + delta[k];
+    for (size_t k = tid; k < tsz; k += blockDim.x) {
+      const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+      const double* zs = cur + (size_t)i * n;
+      const double* dz = xs + i * 16;
+      trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
+    }
     return;
   }
   // ---- Powell dogleg point for trust radius pb.lambda[b]
@@ -656,11 +574,19 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* 
     q = 0.5 * gn;
   }
   double xn = 0.0;
+  __syncthreads();
   for (size_t k = tid; k < tsz; k += blockDim.x) {
     const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
     const double x = cu * gv[i * 16 + rho] + cn * delta[k];
-    trial[k] = cur[k] + x;
+    xs[i * 16 + rho] = x;
     xn = fma(x, x, xn);
+  }
+  __syncthreads();
+  for (size_t k = tid; k < tsz; k += blockDim.x) {
+    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+    const double* zs = cur + (size_t)i * n;
+    const double* dz = xs + i * 16;
+    trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
   }
   xn = block_sum(xn, red, tid);
   if (tid == 0) {

@@ -241,6 +241,83 @@ struct Kin {
   }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Pose2 (GTSAM semantics; restated in the oracle as well): the Lie part of
+// Pose2Vector = Pose2 x R^k states [x, y, theta, q...]  (gpmp2/geometry/Pose2Vector.h:26-73).
+// ---------------------------------------------------------------------------------------------
+struct P2 {
+  double x, y, th;
+};
+__device__ __forceinline__ double wrap_angle(double c, double s) { return atan2(s, c); }
+// between(a, b) = a^-1 * b
+__device__ __forceinline__ P2 pose2_between(const P2& a, const P2& b) {
+  double sa, ca;
+  sincos(a.th, &sa, &ca);
+  const double dx = b.x - a.x, dy = b.y - a.y;
+  double sd, cd;
+  sincos(b.th - a.th, &sd, &cd);
+  return P2{ca * dx + sa * dy, -sa * dx + ca * dy, wrap_angle(cd, sd)};
+}
+// Pose2::Logmap
+__device__ __forceinline__ void pose2_logmap(const P2& p, double (&v)[3]) {
+  const double w = p.th;
+  if (fabs(w) < 1e-10) {
+    v[0] = p.x; v[1] = p.y; v[2] = w;
+  } else {
+    double s, c;
+    sincos(w, &s, &c);
+    const double c_1 = c - 1.0, det = c_1 * c_1 + s * s;
+    const double ux = c * p.x + s * p.y - p.x, uy = -s * p.x + c * p.y - p.y;
+    v[0] = (w / det) * (-uy);
+    v[1] = (w / det) * ux;
+    v[2] = w;
+  }
+}
+// Pose2::AdjointMap (row-major 3x3)
+__device__ __forceinline__ void pose2_adjoint(const P2& p, double (&A)[9]) {
+  double s, c;
+  sincos(p.th, &s, &c);
+  A[0] = c; A[1] = -s; A[2] = p.y; A[3] = s; A[4] = c; A[5] = -p.x; A[6] = 0; A[7] = 0; A[8] = 1;
+}
+__device__ __forceinline__ P2 pose2_inverse(const P2& a) {
+  double s, c;
+  sincos(a.th, &s, &c);
+  return P2{-(c * a.x + s * a.y), -(-s * a.x + c * a.y), wrap_angle(c, -s)};
+}
+// Pose2::LogmapDerivative
+__device__ __forceinline__ void pose2_logmap_derivative(const P2& p, double (&J)[9]) {
+  double v[3];
+  pose2_logmap(p, v);
+  const double alpha = v[2];
+  if (fabs(alpha) > 1e-5) {
+    const double ai = 1 / alpha, hc = 0.5 * sin(alpha) / (1 - cos(alpha));
+    J[0] = alpha * hc; J[1] = -0.5 * alpha; J[2] = v[0] * ai - v[0] * hc + 0.5 * v[1];
+    J[3] = 0.5 * alpha; J[4] = alpha * hc; J[5] = v[1] * ai - 0.5 * v[0] - v[1] * hc;
+    J[6] = 0; J[7] = 0; J[8] = 1;
+  } else {
+    J[0] = 1; J[1] = 0; J[2] = 0.5 * v[1]; J[3] = 0; J[4] = 1; J[5] = -0.5 * v[0]; J[6] = 0; J[7] = 0; J[8] = 1;
+  }
+}
+__device__ __forceinline__ void mat3_mul(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+// Values::retract of one state component: Pose2 first-order chart on the first three coordinates
+// (gtsam Pose2::ChartAtOrigin::Retract, non-SLOW build) composed on the right, '+' elsewhere
+// (gpmp2/geometry/ProductDynamicLieGroup.h:84-90).  z = the state's first three coordinates.
+__device__ __forceinline__ double retract_coord(bool lie, int rho, const double* z, const double* dz) {
+  if (!lie || rho > 2) return z[rho] + dz[rho];
+  double s, c;
+  sincos(z[2], &s, &c);
+  if (rho == 0) return z[0] + c * dz[0] - s * dz[1];
+  if (rho == 1) return z[1] + s * dz[0] + c * dz[1];
+  double sd, cd;
+  sincos(dz[2], &sd, &cd);
+  return wrap_angle(c * cd - s * sd, s * cd + c * sd);
+}
+
 // stage the robot model into LDS (every thread of the block must call this)
 __device__ __forceinline__ void stage_robot(RobotDev* dst_lds, const RobotDev* __restrict__ src) {
   const int n = sizeof(RobotDev) / 4;

@@ -10,7 +10,7 @@ constexpr int TILE = 16;   // block-tridiagonal tile edge (n = 2*dof <= 16 in th
 
 // Uniform parameters of a plan; lives in HBM, read through scalar loads.
 struct PlanParams {
-  int B, N, I, P, Ppad, D, n, NG, REC, Npad;
+  int B, N, I, P, Ppad, D, n, NG, REC, Npad, GPREC;
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;

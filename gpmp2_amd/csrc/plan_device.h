@@ -21,11 +21,17 @@ __device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuff
     const double z = tr[idx];
     if (i == 0 || i == N) {
       const double* tg = (i == 0) ? (a ? pb.start_vel : pb.start_conf) : (a ? pb.end_vel : pb.end_conf);
-      const double d = z - tg[(size_t)b * D + k];
+      tg += (size_t)b * D;
+      double d = z - tg[k];
+      if (P.lie && !a && k < 3) {  // -Local(x, prior) of PriorFactor<Pose2Vector>
+        const double* zs = tr + (size_t)i * n;
+        const P2 bt = pose2_between(P2{zs[0], zs[1], zs[2]}, P2{tg[0], tg[1], tg[2]});
+        d = -(k == 0 ? bt.x : k == 1 ? bt.y : bt.th);
+      }
       acc += (a ? P.vel_prior_w : P.conf_prior_w) * d * d;
     }
     double H;
-    if (!a && P.flag_pos_limit) {
+    if (!a && P.flag_pos_limit && !(P.lie && k < 3)) {
       const double e = hinge_limit(z, P.pos_lo[k], P.pos_hi[k], P.pos_th[k], H);
       acc += P.pos_w[k] * e * e;
     }
@@ -46,7 +52,7 @@ __device__ __forceinline__ double total_error(const PlanParams& P, const PlanBuf
   const double* eb = rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
   double acc = 0.0;
   for (int p = lane; p < P.P; p += 64) acc += eb[p];
-  const double* gb = gpu + ((size_t)b * (P.n + 1) + P.n) * P.Npad;
+  const double* gb = gpu + ((size_t)b * P.GPREC + P.n) * P.Npad;
   for (int i = 1 + lane; i <= P.N; i += 64) acc += gb[i];
   return 0.5 * (wave_sum(acc) + misc_error(P, pb, b, tr, lane));
 }

@@ -102,14 +102,41 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   for (int k = 0; k < D; k++) rb[(size_t)(NG + k) * P.Ppad] = gv[k] * w;
   rb[(size_t)(NG + D) * P.Ppad] = e * w;
 
-  // GaussianProcessPriorLinear of the interval ending at state i: r = Phi z_{i-1} - z_i,
-  // u = Q^-1 r (Q^-1 = B(dt) (x) Qc^-1), energy r^T u.   gp/GaussianProcessPriorLinear.h:57-83
+  // GP prior of the interval ending at state i.  Vector spaces: GaussianProcessPriorLinear
+  // (gp/GaussianProcessPriorLinear.h:57-83) r = Phi z_{i-1} - z_i.  Pose2 robots:
+  // GaussianProcessPriorLie<Pose2Vector> (gp/GaussianProcessPriorLie.h:61-86)
+  // r = [Log(x1^-1 x2) - v1 dt ; v2 - v1] plus the pose blocks of its Jacobians.
+  // Both: u = Q^-1 r (Q^-1 = B(dt) (x) Qc^-1), energy r^T u.
   if (unary && i > 0) {
     double rx[D], rv[D], sx[D], sv[D];
+    double* gb = gpu + (size_t)b * P.GPREC * P.Npad + i;
+    if constexpr (K::BASE == 3) {
+      const P2 p1{x0[0], x0[1], x0[2]}, p2{x1[0], x1[1], x1[2]};
+      const P2 bt = pose2_between(p1, p2);
+      double lg[3], Hinv[9], Hc1[9], Hlog[9], T[9], J1[9];
+      pose2_logmap(bt, lg);
+      pose2_adjoint(p1, Hinv);                  // Inverse: H = -Ad(p1)
+      pose2_adjoint(pose2_inverse(p2), Hc1);    // Compose(a, b): H1 = Ad(b^-1)
+      pose2_logmap_derivative(bt, Hlog);
+      mat3_mul(Hlog, Hc1, T);
+      mat3_mul(T, Hinv, J1);
 #pragma unroll
-    for (int k = 0; k < D; k++) {
-      rx[k] = x0[k] + P.delta_t * v0[k] - x1[k];
-      rv[k] = v0[k] - v1[k];
+      for (int k = 0; k < 9; k++) {
+        gb[(size_t)(n + 1 + k) * P.Npad] = -J1[k];
+        gb[(size_t)(n + 1 + 9 + k) * P.Npad] = Hlog[k];
+      }
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        const double r = (k < 3) ? lg[k] : (x1[k] - x0[k]);
+        rx[k] = r - v0[k] * P.delta_t;
+        rv[k] = v1[k] - v0[k];
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        rx[k] = x0[k] + P.delta_t * v0[k] - x1[k];
+        rv[k] = v0[k] - v1[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < D; k++) {
@@ -122,7 +149,6 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
       sx[k] = ax;
       sv[k] = av;
     }
-    double* gb = gpu + (size_t)b * (n + 1) * P.Npad + i;
     double en = 0.0;
 #pragma unroll
     for (int k = 0; k < D; k++) {
@@ -349,42 +375,31 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
   constexpr int n = 2 * D;
   using Asm = Assembler<D>;
   const PlanParams& P = *pp;
-  const int b = blockIdx.x, lane = threadIdx.x, c = lane & 15, g = lane >> 4, N = P.N;
-  const double* tr = traj + (size_t)b * (N + 1) * n;
+  const int N = P.N;
+  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
   __shared__ typename Asm::Slot slots[2];
   Asm as(P, pb, rec_of(pb, pb.which[b], bufsel), gpu_of(pb, pb.which[b], bufsel), b, lane);
-  double pf[Asm::NROUND];
-  as.prefetch(0, pf);
-  as.commit(0, pf, slots[0]);
-  as.prefetch(1, pf);
-  as.commit(1, pf, slots[1]);
+  as.stage(i, slots[0]);
+  as.stage(i + 1, slots[1]);
   __syncthreads();
-  for (int i = 0; i <= N; i++) {
-    double zi[4];
+  Tile S, Cl, Cr;
+  as.build_tiles(i, slots[0], slots[1], traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr);
 #pragma unroll
-    for (int k = 0; k < 4; k++) zi[k] = (g + 4 * k < n) ? tr[(size_t)i * n + g + 4 * k] : 0.0;
-    Tile Dt, Wt;
-    as.build(i, slots[i & 1], slots[(i + 1) & 1], zi, Dt, Wt);
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int rho = g + 4 * k;
-      if (rho < n && c < n) {
-        if (Hd) Hd[(((size_t)b * (N + 1) + i) * n + rho) * n + c] = Dt.r[k];
-        // H_{i,i+1}[rho][c] is block (i, i+1); the ABI exports block (i+1, i) = its transpose
-        if (Ho && i < N) Ho[(((size_t)b * N + i) * n + c) * n + rho] = Wt.r[k];
-      }
-      if (rho < n && c == RHSCOL && gout) gout[((size_t)b * (N + 1) + i) * n + rho] = -Wt.r[k];
+  for (int k = 0; k < 4; k++) {
+    const int rho = g + 4 * k;
+    if (rho < n && c < n) {
+      if (Hd) Hd[(((size_t)b * (N + 1) + i) * n + rho) * n + c] = S.r[k];
+      // the ABI exports block (i+1, i) = H_{i,i+1}^T; also check it against the left coupling of i+1
+      if (Ho && i < N) Ho[(((size_t)b * N + i) * n + c) * n + rho] = Cr.r[k];
     }
-    as.prefetch(i + 2, pf);
-    as.commit(i + 2, pf, slots[i & 1]);
-    __syncthreads();
+    if (rho < n && c == RHSCOL && gout) gout[((size_t)b * (N + 1) + i) * n + rho] = -S.r[k];
   }
 }
 
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                             double* Hd, double* Ho, double* g, hipStream_t st) {
-  const dim3 grid(hp.B), block(64);
+  const dim3 grid(hp.B * (hp.N + 1)), block(64);
   switch (hp.D) {
 #define G2_EXP_CASE(DD) \
   case DD: k_export_normal_eq<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g); break;

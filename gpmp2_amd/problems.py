@@ -182,3 +182,40 @@ def point_robot_2d():
     z = np.zeros((1, 2))
     return Problem("point_robot_2d", model, [d.origin_x, d.origin_y], d.cell_size, field, s, start[None], z.copy(),
                    end[None], z.copy(), init)
+
+
+def mobile_arm_config5():
+    """BASELINE config 5: matlab/MobileArm2FactorGraphExample.m -- SE(2) base + 2-link arm (dof 5),
+    N = 50, no GP interpolation, 2-D MobileMap1 SDF, planar obstacle factor on every state,
+    VehicleDynamicsFactorPose2Vector (sigma 1e-3) on every state, GaussianProcessPriorPose2Vector,
+    Dogleg with GTSAM defaults (deltaInitial 1.0, 100 iterations, relative tol 1e-5, no rollback)."""
+    model = robots.generateMobileArm("SimpleTwoLinksArm")
+    d = datasets.generate2Ddataset("MobileMap1")
+    field = datasets.signedDistanceField2D(d.map, d.cell_size)
+    N = 50
+    s = TrajOptimizerSetting(5)
+    s.set_total_step(N)
+    s.set_total_time(5.0)
+    s.set_obs_check_inter(0)
+    s.set_cost_sigma(0.1)
+    s.set_epsilon(0.1)
+    s.set_conf_prior_model(0.0001)
+    s.set_vel_prior_model(0.0001)
+    s.set_Qc_model(np.eye(5))
+    s.setDogleg()
+    s.dogleg_delta_initial = 1.0
+    s.set_max_iter(100)
+    s.set_rel_thresh(1e-5)
+    s.setOptimizationNoIncrase(False)
+    s.vehicle_dynamics_sigma = 0.001
+    start = np.array([-1.0, 0.0, math.pi / 2, 0.0, 0.0])
+    end = np.array([1.0, 0.0, math.pi / 2, 0.0, 0.0])
+    dt = 5.0 / N
+    avg_vel = np.concatenate([end[:3] - start[:3], (end[3:] / N)]) / dt
+    init = np.zeros((1, N + 1, 10))
+    for i in range(N + 1):
+        init[0, i, :5] = start * (N - i) / N + end * i / N
+        init[0, i, 5:] = avg_vel
+    z = np.zeros((1, 5))
+    return Problem("mobile_arm_config5", model, [d.origin_x, d.origin_y], d.cell_size, field, s, start[None], z.copy(),
+                   end[None], z.copy(), init)

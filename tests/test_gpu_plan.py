@@ -263,3 +263,70 @@ def test_full_size_headline_config_lm(engine, oracle):
     assert list(res["iters"][sel]) == list(ref["iters"])
     np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
     np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ Pose2 (Lie) path, BASELINE config 5
+def test_mobile_arm_factors_vs_oracle(engine, oracle, golden):
+    import gpmp2_amd as g
+    from helpers import num, vec
+    d = golden["pose2_mobile_arm"]
+    arm = g.Arm(2, d["a"], d["alpha"], d["d"])
+    base = g.pose3(g.rot_yaw(num(d["base_T_arm_yaw"])), d["base_T_arm_xyz"])
+    model = g.Pose2MobileArmModel(g.Pose2MobileArm(arm, base),
+                                  [g.BodySphere(0, 0.1, (0.2, 0.1, 0.0)), g.BodySphere(1, 0.1, (-0.5, 0, 0)),
+                                   g.BodySphere(2, 0.1, (-0.3, 0.1, 0.05)), g.BodySphere(2, 0.1, (0, 0, 0))])
+    r, ro = engine.robot(model), oracle.robot(model)
+    for c in d["cases"]:                                   # the reference's literal link poses
+        poses, _ = engine.forward_kinematics(r, vec(c["q"]))
+        for l in range(3):
+            np.testing.assert_allclose(poses[0, l], g.pose3(g.rot_yaw(num(c["yaw"][l])), c["xyz"][l]), atol=d["tol"])
+    q = np.random.default_rng(21).uniform(-2, 2, size=(64, 5))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-9)
+    p = problems.mobile_arm_config5()
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    q = np.random.default_rng(22).uniform([-4, -4, -3, -2, -2], [4, 4, 3, 2, 2], size=(256, 5))
+    (ea, ha), (eb, hb) = engine.obstacle_factor(r, s, 0.1, q), oracle.obstacle_factor(ro, so, 0.1, q)
+    assert (eb > 0).sum() > 10
+    np.testing.assert_allclose(ea, eb, atol=1e-9)
+    np.testing.assert_allclose(ha, hb, atol=1e-8)
+
+
+def test_config5_linearize_matches_oracle(engine, oracle):
+    p = problems.mobile_arm_config5()
+    rng = np.random.default_rng(23)
+    traj = p.init + 0.2 * rng.normal(size=p.init.shape)     # rotate / shift the base so the Lie blocks are non-trivial
+    r, s, ro, so = _handles(engine, oracle, p)
+    a = engine.linearize(r, s, p.setting, *_args(p), traj)
+    b = oracle.linearize(ro, so, p.setting, *_args(p), traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+
+
+@pytest.mark.parametrize("opt", ["DOGLEG", "GN", "LM"])
+def test_config5_mobile_arm_solve_matches_oracle(engine, oracle, opt):
+    """MobileArm2FactorGraphExample: Pose2Vector states, GaussianProcessPriorPose2Vector, planar obstacle
+    factor and VehicleDynamicsFactorPose2Vector on every state; Dogleg is the script's optimizer."""
+    p = problems.mobile_arm_config5()
+    {"DOGLEG": p.setting.setDogleg, "GN": p.setting.setGaussNewton, "LM": p.setting.setLM}[opt]()
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_config4_receding_horizon_windows(engine, oracle):
+    """BASELINE config 4: windows warm-started from the solved trajectory, 3 fixed GN iterations."""
+    base = problems.wam_restarts(B=1, total_step=20, obs_check_inter=3, sdf="40")
+    r, s, ro, so = _handles(engine, oracle, base)
+    sol = engine.batch_optimize(r, s, base.setting, *_args(base), base.init)["traj"][0]
+    p = problems.wam_windows(sol, B=6, total_step=20, obs_check_inter=3, fixed_iterations=3, sdf="40")
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    assert list(res["iters"]) == [3] * 6 == list(ref["iters"])
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
