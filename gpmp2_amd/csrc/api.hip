@@ -468,7 +468,6 @@ int gpmp2mi_obstacle_gp_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, dou
                                double* H3, double* H4) {
   (void)Qc;  // Lambda / Psi do not depend on Qc (pinned by tests/test_oracle_known_answers.py)
   G2_CHECK(r && s && c1 && v1 && c2 && v2 && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
-  G2_CHECK(r->h.base_dof == 0, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP interpolation is not built yet");
   const bool jac = H1 || H2 || H3 || H4;
   G2_CHECK(!jac || (H1 && H2 && H3 && H4), GPMP2MI_ERR_INVALID, "pass all four Jacobians or none");
   if (M == 0) return GPMP2MI_OK;
@@ -500,7 +499,6 @@ int gpmp2mi_gp_prior_factor(int D, int lie, double dt, int M, const double* c1, 
                             const double* c2, const double* v2, double* err, double* H1, double* H2,
                             double* H3, double* H4) {
   G2_CHECK(c1 && v1 && c2 && v2 && err && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");
-  G2_CHECK(!lie, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP prior is not built yet");
   const bool jac = H1 || H2 || H3 || H4;
   G2_CHECK(!jac || (H1 && H2 && H3 && H4), GPMP2MI_ERR_INVALID, "pass all four Jacobians or none");
   if (M == 0) return GPMP2MI_OK;
@@ -517,7 +515,8 @@ int gpmp2mi_gp_prior_factor(int D, int lie, double dt, int M, const double* c1, 
     G2_TRY(h3.alloc((size_t)M * 2 * D * D));
     G2_TRY(h4.alloc((size_t)M * 2 * D * D));
   }
-  G2_TRY(launch_gp_prior_linear(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
+  if (lie) G2_TRY(launch_gp_prior_lie(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
+  else G2_TRY(launch_gp_prior_linear(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(de.download(err));
   G2_TRY(h1.download(H1));
@@ -531,7 +530,6 @@ int gpmp2mi_gp_interpolate(int D, int lie, const double* Qc, double dt, double t
                            const double* v1, const double* c2, const double* v2, double* conf, double* vel) {
   (void)Qc;
   G2_CHECK(c1 && v1 && c2 && v2 && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");
-  G2_CHECK(!lie, GPMP2MI_ERR_UNSUPPORTED, "Pose2 GP interpolation is not built yet");
   if (M == 0) return GPMP2MI_OK;
   G2_TRY(ensure_device());
   DevBuf<double> a, b, c, d, oc, ov;
@@ -541,7 +539,8 @@ int gpmp2mi_gp_interpolate(int D, int lie, const double* Qc, double dt, double t
   G2_TRY(d.upload(v2, (size_t)M * D));
   if (conf) G2_TRY(oc.alloc((size_t)M * D));
   if (vel) G2_TRY(ov.alloc((size_t)M * D));
-  G2_TRY(launch_gp_interp_linear(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
+  if (lie) G2_TRY(launch_gp_interp_lie(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
+  else G2_TRY(launch_gp_interp_linear(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(oc.download(conf));
   G2_TRY(ov.download(vel));
@@ -602,8 +601,6 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
-  G2_CHECK(robot->h.base_dof == 0 || s->obs_check_inter == 0, GPMP2MI_ERR_UNSUPPORTED,
-           "Pose2 robots: GP-interpolated obstacle factors (obs_check_inter > 0) are not built yet");
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
            "unknown opt_type");
   G2_CHECK(s->cost_sigma > 0 && s->conf_prior_sigma > 0 && s->vel_prior_sigma > 0, GPMP2MI_ERR_INVALID,
@@ -626,7 +623,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.D = D;
   P.n = 2 * D;
   P.NG = D * (D + 1) / 2;
-  P.REC = P.NG + D + 1;
+  P.REC = P.NG + D + 1 + ((robot->h.base_dof == 3 && P.I > 0) ? 36 : 0);
   P.Npad = (P.N + 1 + 63) / 64 * 64;
   P.lie = robot->h.base_dof == 3 ? 1 : 0;
   P.GPREC = P.n + 1 + (P.lie ? 18 : 0);

@@ -19,11 +19,13 @@ template <int D>
 struct Assembler {
   static constexpr int n = 2 * D, NG = D * (D + 1) / 2, RECP = NG + D + 1;  // per-point record
   static constexpr int GPN = n + 1 + GP_EXTRA_LIE;
+  static constexpr int PT_EXTRA_LIE = 36;  // M1..M4 (3x3 pose blocks of the interpolation Jacobians)
+  static constexpr int RECMAX = RECP + PT_EXTRA_LIE;
 
   // LDS image of one interval: pts[jj][RECP] for jj = 0..I (I = unary of the end state), then
   // the GP record: u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)]
   struct Slot {
-    double pts[MAXI + 1][RECP];
+    double pts[MAXI + 1][RECMAX];
     double gp[GPN];
   };
 
@@ -58,7 +60,7 @@ struct Assembler {
   __device__ __forceinline__ void stage(int iv, Slot& s) const {
     const int I = P.I;
     const int npt = (iv == 0) ? 1 : I + 1;
-    const int nv = RECP * npt;
+    const int nv = P.REC * npt;
     const int p0 = (iv == 0) ? 0 : 1 + (iv - 1) * (I + 1);
     const double* rb = rec + (size_t)b * P.REC * P.Ppad;
     const double* gb = gpu + (size_t)b * P.GPREC * P.Npad;
@@ -90,6 +92,30 @@ struct Assembler {
     return acc;
   }
 
+  // packed upper-triangular lookup of the point's G = J^T J / sigma^2
+  __device__ __forceinline__ static double Gat(const double* pt, int a, int bb) {
+    const int lo = min(a, bb), hi = max(a, bb);
+    return pt[lo * D - (lo * (lo - 1)) / 2 + (hi - lo)];
+  }
+  // (Hint_L^T G Hint_R)[kr][kc] for Hint = diag(M (3x3), s I): Pose2 interpolated obstacle factor
+  __device__ __forceinline__ static double hint_quad(const double* pt, const double* ML, double sL,
+                                                     const double* MR, double sR, int kr, int kc) {
+    double acc = 0.0;
+    const int a0 = kr < 3 ? 0 : kr, a1 = kr < 3 ? 3 : kr + 1;
+    const int b0 = kc < 3 ? 0 : kc, b1 = kc < 3 ? 3 : kc + 1;
+    for (int a = a0; a < a1; a++) {
+      const double la = kr < 3 ? ML[a * 3 + kr] : sL;
+      for (int bb = b0; bb < b1; bb++) acc = fma(la * (kc < 3 ? MR[bb * 3 + kc] : sR), Gat(pt, a, bb), acc);
+    }
+    return acc;
+  }
+  // (Hint^T g)[kr]
+  __device__ __forceinline__ static double hint_vec(const double* pt, const double* M, double s, int kr) {
+    const double* gp_ = pt + NG;
+    if (kr >= 3) return s * gp_[kr];
+    return M[0 * 3 + kr] * gp_[0] + M[1 * 3 + kr] * gp_[1] + M[2 * 3 + kr] * gp_[2];
+  }
+
   // Tiles of block i: S = [D_i | -g_i in column RHSCOL], Cl = H_{i,i-1}, Cr = H_{i,i+1}; returns this
   // lane's share of the block's graph-error contribution (to be wave-summed; not yet halved).
   // si = slot of interval i (its unary point is state i), sn = slot of interval i+1; z = state i.
@@ -107,6 +133,7 @@ struct Assembler {
       double d = 0.0, hr = 0.0, hl = 0.0;
       if (valid[k]) {
         const int ar = a_row[k], ac = a_col, t = tri[k], kr = k_row[k], kc = k_col, rho = g + 4 * k;
+        (void)t;
         if (!lie) {
           // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
           // KO = -Phi^T Q^-1 = H_{i,i+1}
@@ -132,6 +159,22 @@ struct Assembler {
           const GpCoef cf = P.coef[jj];
           const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
           const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
+          if (lie) {
+            // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
+            if (has_prev) {
+              const double* pt = si.pts[jj];
+              const double* M = pt + RECP;
+              d += hint_quad(pt, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
+              hl += hint_quad(pt, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
+            }
+            if (has_next) {
+              const double* pt = sn.pts[jj];
+              const double* M = pt + RECP;
+              d += hint_quad(pt, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
+              hr += hint_quad(pt, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
+            }
+            continue;
+          }
           if (has_prev) {
             const double Gp = si.pts[jj][t];
             d = fma(w2r * w2c, Gp, d);
@@ -203,6 +246,11 @@ struct Assembler {
         if (!ar) gg += si.pts[I][NG + kr];
         for (int jj = 0; jj < I; jj++) {
           const GpCoef cf = P.coef[jj];
+          if (lie) {
+            if (has_prev) gg += hint_vec(si.pts[jj], si.pts[jj] + RECP + (ar ? 27 : 18), ar ? cf.p12 : cf.p11, kr);
+            if (has_next) gg += hint_vec(sn.pts[jj], sn.pts[jj] + RECP + (ar ? 9 : 0), ar ? cf.l12 : cf.l11, kr);
+            continue;
+          }
           if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pts[jj][NG + kr], gg);
           if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pts[jj][NG + kr], gg);
         }

@@ -298,12 +298,82 @@ __device__ __forceinline__ void pose2_logmap_derivative(const P2& p, double (&J)
     J[0] = 1; J[1] = 0; J[2] = 0.5 * v[1]; J[3] = 0; J[4] = 1; J[5] = -0.5 * v[0]; J[6] = 0; J[7] = 0; J[8] = 1;
   }
 }
+// Pose2::Expmap
+__device__ __forceinline__ P2 pose2_expmap(const double (&v)[3]) {
+  const double w = v[2];
+  if (fabs(w) < 1e-10) return P2{v[0], v[1], v[2]};
+  double s, c;
+  sincos(w, &s, &c);
+  const double ox = -v[1], oy = v[0];
+  const double rx = c * ox - s * oy, ry = s * ox + c * oy;
+  return P2{(ox - rx) / w, (oy - ry) / w, wrap_angle(c, s)};
+}
+// Pose2::ExpmapDerivative
+__device__ __forceinline__ void pose2_expmap_derivative(const double (&v)[3], double (&J)[9]) {
+  const double alpha = v[2];
+  if (fabs(alpha) > 1e-5) {
+    const double sZ = sin(alpha) / alpha, c1Z = (cos(alpha) - 1) / alpha;
+    const double v1Z = v[0] / alpha, v2Z = v[1] / alpha;
+    J[0] = sZ; J[1] = -c1Z; J[2] = v1Z + v2Z * c1Z - v1Z * sZ;
+    J[3] = c1Z; J[4] = sZ; J[5] = -v1Z * c1Z + v2Z - v2Z * sZ;
+    J[6] = 0; J[7] = 0; J[8] = 1;
+  } else {
+    J[0] = 1; J[1] = 0; J[2] = -0.5 * v[1]; J[3] = 0; J[4] = 1; J[5] = 0.5 * v[0]; J[6] = 0; J[7] = 0; J[8] = 1;
+  }
+}
+__device__ __forceinline__ P2 pose2_compose(const P2& a, const P2& b) {
+  double s, c, sb, cb;
+  sincos(a.th, &s, &c);
+  sincos(b.th, &sb, &cb);
+  return P2{a.x + c * b.x - s * b.y, a.y + s * b.x + c * b.y, wrap_angle(c * cb - s * sb, s * cb + c * sb)};
+}
 __device__ __forceinline__ void mat3_mul(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
 #pragma unroll
     for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
 }
+// GaussianProcessInterpolatorLie<Pose2Vector>::interpolatePose  gp/GaussianProcessInterpolatorLie.h:64-100
+// for states [x, y, theta, q...].  Lambda / Psi are (2x2) (x) I, so the arm part is the linear
+// interpolation and only the 3x3 pose blocks M1..M4 of the four Jacobians are non-trivial:
+//   Hint_k = diag(M_k, s_k I),  s = (l11, l12, p11, p12).
+template <int D>
+__device__ __forceinline__ void lie_interpolate(const GpCoef& c, const double (&x0)[D], const double (&v0)[D],
+                                                const double (&x1)[D], const double (&v1)[D], double (&q)[D],
+                                                double (*M)[9] /* [4][9] or nullptr */) {
+  const P2 p1{x0[0], x0[1], x0[2]}, p2{x1[0], x1[1], x1[2]};
+  const P2 bt = pose2_between(p1, p2);
+  double lg[3];
+  pose2_logmap(bt, lg);
+  double xi[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) xi[k] = c.l12 * v0[k] + c.p11 * lg[k] + c.p12 * v1[k];
+  const P2 e = pose2_expmap(xi);
+  const P2 p = pose2_compose(p1, e);
+  q[0] = p.x; q[1] = p.y; q[2] = p.th;
+#pragma unroll
+  for (int k = 3; k < D; k++) q[k] = x0[k] + (c.l12 * v0[k] + c.p11 * (x1[k] - x0[k]) + c.p12 * v1[k]);
+  if (!M) return;
+  double E[9], L[9], Hinv[9], Hc1[9], Hc21[9], T[9], U[9];
+  pose2_expmap_derivative(xi, E);
+  pose2_logmap_derivative(bt, L);
+  pose2_adjoint(p1, Hinv);                  // Inverse: -Ad(p1)
+  pose2_adjoint(pose2_inverse(p2), Hc1);    // Compose H1 = Ad(p2^-1)
+  pose2_adjoint(pose2_inverse(e), Hc21);    // Compose(p1, e) H1 = Ad(e^-1)
+  mat3_mul(E, L, T);                        // Hexp * Hlog
+  mat3_mul(T, Hc1, U);
+  mat3_mul(U, Hinv, T);                     // Hexp Hlog Hcomp1 Ad(p1)  (sign applied below)
+  double EL[9];
+  mat3_mul(E, L, EL);
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    M[0][k] = Hc21[k] - c.p11 * T[k];
+    M[1][k] = c.l12 * E[k];
+    M[2][k] = c.p11 * EL[k];
+    M[3][k] = c.p12 * E[k];
+  }
+}
+
 // Values::retract of one state component: Pose2 first-order chart on the first three coordinates
 // (gtsam Pose2::ChartAtOrigin::Retract, non-SLOW build) composed on the right, '+' elsewhere
 // (gpmp2/geometry/ProductDynamicLieGroup.h:84-90).  z = the state's first three coordinates.

@@ -245,27 +245,44 @@ __global__ void k_obstacle_gp(const RobotDev* __restrict__ Rg, SdfDev sdf, doubl
   stage_robot(&R, Rg);
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= M) return;
-  double q[D];
+  double q[D], Ml[4][9];
+  if constexpr (K::BASE == 3) {
+    // GaussianProcessInterpolatorPose2Vector  gp/GaussianProcessInterpolatorLie.h:64-100
+    double x0[D], w0[D], x1[D], w1[D];
 #pragma unroll
-  for (int k = 0; k < D; k++) {
-    const size_t o = (size_t)m * D + k;
-    q[k] = gc.l11 * c1[o] + gc.l12 * v1[o] + gc.p11 * c2[o] + gc.p12 * v2[o];
+    for (int k = 0; k < D; k++) {
+      const size_t o = (size_t)m * D + k;
+      x0[k] = c1[o]; w0[k] = v1[o]; x1[k] = c2[o]; w1[k] = v2[o];
+    }
+    lie_interpolate<D>(gc, x0, w0, x1, w1, q, Ml);
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const size_t o = (size_t)m * D + k;
+      q[k] = gc.l11 * c1[o] + gc.l12 * v1[o] + gc.p11 * c2[o] + gc.p12 * v2[o];
+    }
   }
   const int S = R.nr_spheres;
+  const double sc[4] = {gc.l11, gc.l12, gc.p11, gc.p12};
+  double* Hs[4] = {H1, H2, H3, H4};
   K::for_each_sphere(R, q, [&](int s, const double (&p)[3], const double (&Jc)[D][3], int) {
     double hx, hy, hz;
     const double e = hinge_obstacle<SDIM>(sdf, p[0], p[1], p[2], R.sph_r[s] + eps, hx, hy, hz);
     const int so = R.sph_orig[s];
     err[(size_t)m * S + so] = e;
-    if (H1)
+    if (!H1) return;
+    double Jr[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) Jr[k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
+#pragma unroll
+    for (int t = 0; t < 4; t++)
 #pragma unroll
       for (int k = 0; k < D; k++) {
-        const double j = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
-        const size_t o = ((size_t)m * S + so) * D + k;
-        H1[o] = j * gc.l11;
-        H2[o] = j * gc.l12;
-        H3[o] = j * gc.p11;
-        H4[o] = j * gc.p12;
+        double v = Jr[k] * sc[t];
+        if constexpr (K::BASE == 3) {
+          if (k < 3) v = Jr[0] * Ml[t][0 * 3 + k] + Jr[1] * Ml[t][1 * 3 + k] + Jr[2] * Ml[t][2 * 3 + k];
+        }
+        Hs[t][((size_t)m * S + so) * D + k] = v;
       }
   });
 }
@@ -307,6 +324,77 @@ __global__ void k_gp_interp_linear(int D, GpCoef gc, int M, const double* __rest
     const size_t o = (size_t)m * D + k;
     if (conf) conf[o] = gc.l11 * c1[o] + gc.l12 * v1[o] + gc.p11 * c2[o] + gc.p12 * v2[o];
     if (vel) vel[o] = gc.l21 * c1[o] + gc.l22 * v1[o] + gc.p21 * c2[o] + gc.p22 * v2[o];
+  }
+}
+
+// GaussianProcessPriorLie<Pose2Vector>::evaluateError  gp/GaussianProcessPriorLie.h:61-86
+// states [x, y, theta, q...]; err [2D]; H1..H4 [2D][D]
+template <int D>
+__global__ void k_gp_prior_lie(double dt, int M, const double* __restrict__ c1, const double* __restrict__ v1,
+                               const double* __restrict__ c2, const double* __restrict__ v2,
+                               double* __restrict__ err, double* __restrict__ H1, double* __restrict__ H2,
+                               double* __restrict__ H3, double* __restrict__ H4) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const double* x0 = c1 + (size_t)m * D;
+  const double* x1 = c2 + (size_t)m * D;
+  const P2 p1{x0[0], x0[1], x0[2]}, p2{x1[0], x1[1], x1[2]};
+  const P2 bt = pose2_between(p1, p2);
+  double lg[3], Hinv[9], Hc1[9], Hlog[9], T[9], J1[9];
+  pose2_logmap(bt, lg);
+  pose2_adjoint(p1, Hinv);
+  pose2_adjoint(pose2_inverse(p2), Hc1);
+  pose2_logmap_derivative(bt, Hlog);
+  mat3_mul(Hlog, Hc1, T);
+  mat3_mul(T, Hinv, J1);
+  for (int k = 0; k < D; k++) {
+    const double r = (k < 3) ? lg[k] : (x1[k] - x0[k]);
+    err[(size_t)m * 2 * D + k] = r - v1[(size_t)m * D + k] * dt;
+    err[(size_t)m * 2 * D + D + k] = v2[(size_t)m * D + k] - v1[(size_t)m * D + k];
+  }
+  if (!H1) return;
+  const size_t hb = (size_t)m * 2 * D * D;
+  for (int i = 0; i < 2 * D * D; i++) H1[hb + i] = H2[hb + i] = H3[hb + i] = H4[hb + i] = 0.0;
+  for (int r = 0; r < D; r++)
+    for (int c = 0; c < D; c++) {
+      double a = 0.0, b = 0.0;
+      if (r < 3 && c < 3) { a = -J1[r * 3 + c]; b = Hlog[r * 3 + c]; }
+      else if (r == c) { a = -1.0; b = 1.0; }
+      H1[hb + (size_t)r * D + c] = a;
+      H3[hb + (size_t)r * D + c] = b;
+    }
+  for (int k = 0; k < D; k++) {
+    H2[hb + (size_t)k * D + k] = -dt;
+    H2[hb + (size_t)(D + k) * D + k] = -1.0;
+    H4[hb + (size_t)(D + k) * D + k] = 1.0;
+  }
+}
+
+// GaussianProcessInterpolatorLie<Pose2Vector>::interpolatePose / interpolateVelocity
+// gp/GaussianProcessInterpolatorLie.h:64-146
+template <int D>
+__global__ void k_gp_interp_lie(GpCoef gc, int M, const double* __restrict__ c1, const double* __restrict__ v1,
+                                const double* __restrict__ c2, const double* __restrict__ v2,
+                                double* __restrict__ conf, double* __restrict__ vel) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  double x0[D], w0[D], x1[D], w1[D], q[D];
+  for (int k = 0; k < D; k++) {
+    const size_t o = (size_t)m * D + k;
+    x0[k] = c1[o]; w0[k] = v1[o]; x1[k] = c2[o]; w1[k] = v2[o];
+  }
+  if (conf) {
+    lie_interpolate<D>(gc, x0, w0, x1, w1, q, nullptr);
+    for (int k = 0; k < D; k++) conf[(size_t)m * D + k] = q[k];
+  }
+  if (vel) {
+    const P2 bt = pose2_between(P2{x0[0], x0[1], x0[2]}, P2{x1[0], x1[1], x1[2]});
+    double lg[3];
+    pose2_logmap(bt, lg);
+    for (int k = 0; k < D; k++) {
+      const double r = (k < 3) ? lg[k] : (x1[k] - x0[k]);
+      vel[(size_t)m * D + k] = gc.l22 * w0[k] + gc.p21 * r + gc.p22 * w1[k];
+    }
   }
 }
 
@@ -374,6 +462,31 @@ int launch_gp_prior_linear(int D, double dt, int M, const double* c1, const doub
 int launch_gp_interp_linear(int D, const GpCoef& gc, int M, const double* c1, const double* v1,
                             const double* c2, const double* v2, double* conf, double* vel, hipStream_t st) {
   k_gp_interp_linear<<<G2_GRID(M)>>>(D, gc, M, c1, v1, c2, v2, conf, vel);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_gp_prior_lie(int D, double dt, int M, const double* c1, const double* v1, const double* c2,
+                        const double* v2, double* err, double* H1, double* H2, double* H3, double* H4,
+                        hipStream_t st) {
+  switch (D) {
+#define G2_GPL(DD) case DD: k_gp_prior_lie<DD><<<G2_GRID(M)>>>(dt, M, c1, v1, c2, v2, err, H1, H2, H3, H4); break;
+    G2_GPL(3) G2_GPL(4) G2_GPL(5) G2_GPL(6) G2_GPL(7) G2_GPL(8) G2_GPL(9) G2_GPL(10)
+#undef G2_GPL
+    default: set_error("Pose2Vector dof must be 3..10"); return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_gp_interp_lie(int D, const GpCoef& gc, int M, const double* c1, const double* v1, const double* c2,
+                         const double* v2, double* conf, double* vel, hipStream_t st) {
+  switch (D) {
+#define G2_GIL(DD) case DD: k_gp_interp_lie<DD><<<G2_GRID(M)>>>(gc, M, c1, v1, c2, v2, conf, vel); break;
+    G2_GIL(3) G2_GIL(4) G2_GIL(5) G2_GIL(6) G2_GIL(7) G2_GIL(8) G2_GIL(9) G2_GIL(10)
+#undef G2_GIL
+    default: set_error("Pose2Vector dof must be 3..10"); return GPMP2MI_ERR_UNSUPPORTED;
+  }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

@@ -59,13 +59,20 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     x0[k] = (i > 0) ? z0[k] : 0.0;
     v0[k] = (i > 0) ? z0[D + k] : 0.0;
   }
+  double Mlie[4][9];
+  bool lie_interp = false;
   if (unary) {
 #pragma unroll
     for (int k = 0; k < D; k++) q[k] = x1[k];
   } else {
     const GpCoef c = P.coef[j];
+    if constexpr (K::BASE == 3) {
+      lie_interpolate<D>(c, x0, v0, x1, v1, q, Mlie);   // GaussianProcessInterpolatorPose2Vector
+      lie_interp = true;
+    } else {
 #pragma unroll
-    for (int k = 0; k < D; k++) q[k] = c.l11 * x0[k] + c.l12 * v0[k] + c.p11 * x1[k] + c.p12 * v1[k];
+      for (int k = 0; k < D; k++) q[k] = c.l11 * x0[k] + c.l12 * v0[k] + c.p11 * x1[k] + c.p12 * v1[k];
+    }
   }
 
   double G[NG], gv[D], e = 0.0;
@@ -101,6 +108,14 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
 #pragma unroll
   for (int k = 0; k < D; k++) rb[(size_t)(NG + k) * P.Ppad] = gv[k] * w;
   rb[(size_t)(NG + D) * P.Ppad] = e * w;
+  if constexpr (K::BASE == 3) {
+    if (P.REC > NG + D + 1) {  // pose blocks of the four interpolation Jacobians
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) rb[(size_t)(NG + D + 1 + m * 9 + t) * P.Ppad] = lie_interp ? Mlie[m][t] : 0.0;
+    }
+  }
 
   // GP prior of the interval ending at state i.  Vector spaces: GaussianProcessPriorLinear
   // (gp/GaussianProcessPriorLinear.h:57-83) r = Phi z_{i-1} - z_i.  Pose2 robots:

@@ -330,3 +330,75 @@ def test_config4_receding_horizon_windows(engine, oracle):
     assert list(res["iters"]) == [3] * 6 == list(ref["iters"])
     np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
     np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
+
+
+def test_lie_factor_level_entry_points(engine, oracle, golden):
+    """GaussianProcessPriorPose2Vector / GaussianProcessInterpolatorPose2Vector and the GP-interpolated
+    planar obstacle factor of a Pose2 mobile arm: reference known answers + oracle parity."""
+    d = golden["gp_prior_pose2vector"]
+    for c in d["zero_error_cases"]:
+        err, _ = engine.gp_prior_factor(6, True, d["delta_t"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(err[0], 0.0, atol=d["tol"])
+    gi = golden["gp_interpolator_pose2vector"]
+    for c in gi["cases"]:
+        conf, _ = engine.gp_interpolate(6, True, None, gi["delta_t"], gi["tau"], c["p1"], c["v1"], c["p2"], c["v2"])
+        np.testing.assert_allclose(conf[0], c["expect"], atol=gi["tol"])
+    rng = np.random.default_rng(31)
+    a = [rng.uniform(-2, 2, size=(40, 6)) for _ in range(4)]
+    a[0][0], a[1][0], a[2][0], a[3][0] = (np.array(d["random_case"][k], dtype=float) for k in ("p1", "v1", "p2", "v2"))
+    (ea, Ha), (eb, Hb) = engine.gp_prior_factor(6, True, 0.1, *a), oracle.gp_prior_factor(6, True, 0.1, *a)
+    np.testing.assert_allclose(ea, eb, atol=1e-9)
+    for k in range(4):
+        np.testing.assert_allclose(Ha[k], Hb[k], atol=1e-8)
+    for x, y in zip(engine.gp_interpolate(6, True, None, 0.1, 0.03, *a), oracle.gp_interpolate(6, True, None, 0.1, 0.03, *a)):
+        np.testing.assert_allclose(x, y, atol=1e-9)
+    p = problems.mobile_arm_config5()
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    q = rng.uniform([-3, -3, -3, -2, -2], [3, 3, 3, 2, 2], size=(200, 5))
+    v = rng.normal(size=(200, 5))
+    q2 = q + 0.1 * v + 0.02 * rng.normal(size=(200, 5))
+    v2 = v + 0.1 * rng.normal(size=(200, 5))
+    (ea, Ha), (eb, Hb) = (f(rr, ss, 0.1, None, 0.1, 0.04, q, v, q2, v2) for f, rr, ss in
+                          ((engine.obstacle_gp_factor, r, s), (oracle.obstacle_gp_factor, ro, so)))
+    assert (eb > 0).sum() > 5
+    np.testing.assert_allclose(ea, eb, atol=1e-9)
+    for k in range(4):
+        np.testing.assert_allclose(Ha[k], Hb[k], atol=1e-8)
+
+
+def test_mobile_arm_planner_with_gp_interpolation(engine, oracle):
+    """BatchTrajOptimizePose2MobileArm2D-style graph: Pose2 mobile arm WITH GP-interpolated obstacle
+    factors (obs_check_inter = 3), linearization and a Gauss-Newton / Dogleg solve vs the oracle."""
+    p = problems.mobile_arm_config5()
+    p.setting.set_obs_check_inter(3)
+    p.setting.set_total_step(20)
+    N = 20
+    init = np.zeros((1, N + 1, 10))
+    for i in range(N + 1):
+        init[0, i] = p.init[0, 0] * (N - i) / N + p.init[0, -1] * i / N
+    init[0, :, 5:] = (p.end_conf[0] - p.start_conf[0])[None, :] / 5.0
+    rng = np.random.default_rng(41)
+    traj = init + 0.1 * rng.normal(size=init.shape)
+    r, s, ro, so = _handles(engine, oracle, p)
+    a = engine.linearize(r, s, p.setting, *_args(p), traj)
+    b = oracle.linearize(ro, so, p.setting, *_args(p), traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    for opt in ("GN", "DOGLEG"):
+        {"DOGLEG": p.setting.setDogleg, "GN": p.setting.setGaussNewton}[opt]()
+        res = engine.batch_optimize(r, s, p.setting, *_args(p), init)
+        ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), init)
+        _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_pose2_mobile_base_robot(engine, oracle):
+    import gpmp2_amd as g
+    model = g.Pose2MobileBaseModel(g.Pose2MobileBase(), [g.BodySphere(0, 0.2, (0.1, 0.0, 0.0)), g.BodySphere(0, 0.2, (-0.1, 0.05, 0.0))])
+    r, ro = engine.robot(model), oracle.robot(model)
+    q = np.random.default_rng(51).uniform(-3, 3, size=(32, 3))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-9)
