@@ -601,6 +601,13 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
+  {
+    // k_assemble stages an interval with at most 10 loads per lane (assembler.h NLD)
+    const int nd = D * (D + 1) / 2 + D + 1 + ((robot->h.base_dof == 3 && s->obs_check_inter > 0) ? 36 : 0);
+    const int gpr = 2 * D + 1 + (robot->h.base_dof == 3 ? 18 : 0);
+    G2_CHECK((s->obs_check_inter + 1) * nd + gpr <= 640, GPMP2MI_ERR_UNSUPPORTED,
+             "obs_check_inter too large for the staged assembly");
+  }
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
            "unknown opt_type");
   G2_CHECK(s->cost_sigma > 0 && s->conf_prior_sigma > 0 && s->vel_prior_sigma > 0, GPMP2MI_ERR_INVALID,

@@ -15,19 +15,28 @@ namespace g2 {
 
 constexpr int GP_EXTRA_LIE = 18;  // J1 (9) + J3 (9) appended to the GP record of Pose2 robots
 
-template <int D>
+template <int D, bool LIE>
 struct Assembler {
   static constexpr int n = 2 * D, NG = D * (D + 1) / 2, RECP = NG + D + 1;  // per-point record
   static constexpr int GPN = n + 1 + GP_EXTRA_LIE;
   static constexpr int PT_EXTRA_LIE = 36;  // M1..M4 (3x3 pose blocks of the interpolation Jacobians)
   static constexpr int RECMAX = RECP + PT_EXTRA_LIE;
 
-  // LDS image of one interval: pts[jj][RECP] for jj = 0..I (I = unary of the end state), then
-  // the GP record: u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)]
+  // LDS image of one interval (dynamic shared memory, sized at launch from I and the record
+  // lengths): pts[jj][REC] for jj = 0..I (I = unary of the end state), then the GP record
+  // u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)]
   struct Slot {
-    double pts[MAXI + 1][RECMAX];
-    double gp[GPN];
+    double* base;
+    int rec;   // P.REC
+    int npts;  // I + 1
+    __device__ __forceinline__ double* pt(int jj) const { return base + jj * rec; }
+    __device__ __forceinline__ const double* gpr() const { return base + npts * rec; }
+    __device__ __forceinline__ double* gpw() const { return base + npts * rec; }
   };
+  __host__ __device__ static int slot_doubles(int I, int REC, int GPREC) { return (I + 1) * REC + GPREC; }
+  __device__ __forceinline__ Slot make_slot(double* smem, int which) const {
+    return Slot{smem + which * slot_doubles(P.I, P.REC, P.GPREC), P.REC, P.I + 1};
+  }
 
   const PlanParams& P;
   const PlanBuffers& pb;
@@ -55,22 +64,55 @@ struct Assembler {
     }
   }
 
-  // global -> LDS for interval `iv` (0 = only the unary point of state 0).  Intervals beyond N read
-  // as zeros.
-  __device__ __forceinline__ void stage(int iv, Slot& s) const {
+  // global -> registers -> LDS for the two intervals a block needs (iv and iv + 1; interval 0 is
+  // only the unary point of state 0, intervals beyond N read as zeros).  All loads of both intervals
+  // are issued before the first LDS store so the wavefront pays one memory latency, not one per
+  // 64 values; NLD bounds the per-lane load count (checked on the host).
+  static constexpr int NLD = 10;
+  __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1) const {
     const int I = P.I;
-    const int npt = (iv == 0) ? 1 : I + 1;
-    const int nv = P.REC * npt;
-    const int p0 = (iv == 0) ? 0 : 1 + (iv - 1) * (I + 1);
     const double* rb = rec + (size_t)b * P.REC * P.Ppad;
     const double* gb = gpu + (size_t)b * P.GPREC * P.Npad;
-    const bool in_range = iv <= P.N;
-    for (int v = lane; v < nv + P.GPREC; v += 64) {
-      if (v < nv) {
-        const int k = v / npt, jj = v - k * npt;
-        s.pts[(iv == 0) ? I : jj][k] = in_range ? rb[(size_t)k * P.Ppad + p0 + jj] : 0.0;
-      } else {
-        s.gp[v - nv] = (in_range && iv > 0) ? gb[(size_t)(v - nv) * P.Npad + iv] : 0.0;
+    double val[2][NLD];
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const int ivw = iv + w;
+      const int npt = (ivw == 0) ? 1 : I + 1;
+      const int nv = P.REC * npt;
+      const int p0 = (ivw == 0) ? 0 : 1 + (ivw - 1) * (I + 1);
+      const bool in_range = ivw <= P.N;
+      const float inv_npt = 1.0f / (float)npt;
+#pragma unroll
+      for (int m = 0; m < NLD; m++) {
+        const int v = lane + 64 * m;
+        double x = 0.0;
+        if (in_range && v < nv + P.GPREC) {
+          if (v < nv) {
+            const int k = (int)(((float)v + 0.5f) * inv_npt), jj = v - k * npt;  // exact for v < 2^20
+            x = rb[(size_t)k * P.Ppad + p0 + jj];
+          } else if (ivw > 0) {
+            x = gb[(size_t)(v - nv) * P.Npad + ivw];
+          }
+        }
+        val[w][m] = x;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+      const Slot& s = w ? s1 : s0;
+      const int ivw = iv + w;
+      const int npt = (ivw == 0) ? 1 : I + 1;
+      const int nv = P.REC * npt;
+      const float inv_npt = 1.0f / (float)npt;
+#pragma unroll
+      for (int m = 0; m < NLD; m++) {
+        const int v = lane + 64 * m;
+        if (v < nv) {
+          const int k = (int)(((float)v + 0.5f) * inv_npt), jj = v - k * npt;
+          s.pt((ivw == 0) ? I : jj)[k] = val[w][m];
+        } else if (v < nv + P.GPREC) {
+          s.gpw()[v - nv] = val[w][m];
+        }
       }
     }
   }
@@ -119,83 +161,100 @@ struct Assembler {
   // Tiles of block i: S = [D_i | -g_i in column RHSCOL], Cl = H_{i,i-1}, Cr = H_{i,i+1}; returns this
   // lane's share of the block's graph-error contribution (to be wave-summed; not yet halved).
   // si = slot of interval i (its unary point is state i), sn = slot of interval i+1; z = state i.
+  // want_c: also build the couplings (only odd blocks and the export / Dogleg paths need them).
   __device__ __forceinline__ double build_tiles(int i, const Slot& si, const Slot& sn, const double* z, Tile& S,
-                                                Tile& Cl, Tile& Cr) const {
+                                                Tile& Cl, Tile& Cr, bool want_c) const {
     const int I = P.I, N = P.N;
-    const bool has_prev = i > 0, has_next = i < N, lie = P.lie != 0;
+    const bool has_prev = i > 0, has_next = i < N;
+    constexpr bool lie = LIE;
     const double dt = P.delta_t, w0 = P.Winv[0], w1 = P.Winv[1], w3 = P.Winv[3];
-    const double* J3i = si.gp + n + 1 + 9;   // of interval i   (state i is the second state)
-    const double* J1n = sn.gp + n + 1;       // of interval i+1 (state i is the first state)
-    const double* J1i = si.gp + n + 1;
-    const double* J3n = sn.gp + n + 1 + 9;
+    const double* J3i = si.gpr() + n + 1 + 9;   // of interval i   (state i is the second state)
+    const double* J1n = sn.gpr() + n + 1;       // of interval i+1 (state i is the first state)
+    const double* J1i = si.gpr() + n + 1;
+    const double* J3n = sn.gpr() + n + 1 + 9;
+    double dk[4] = {0, 0, 0, 0}, hrk[4] = {0, 0, 0, 0}, hlk[4] = {0, 0, 0, 0};
+    const int ac = a_col, kc = k_col;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      if (!valid[k]) continue;
+      const int ar = a_row[k], kr = k_row[k], rho = g + 4 * k;
       double d = 0.0, hr = 0.0, hl = 0.0;
-      if (valid[k]) {
-        const int ar = a_row[k], ac = a_col, t = tri[k], kr = k_row[k], kc = k_col, rho = g + 4 * k;
-        (void)t;
-        if (!lie) {
-          // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
-          // KO = -Phi^T Q^-1 = H_{i,i+1}
-          d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
+      if (!lie) {
+        // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
+        // KO = -Phi^T Q^-1 = H_{i,i+1}
+        d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
+        if (want_c) {
           hr = has_next ? P.KO[rho * n + c] : 0.0;
           hl = has_prev ? P.KO[c * n + rho] : 0.0;
-        } else {
-          // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
-          const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
-          if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
-            const double* L = ar ? nullptr : J3i;
-            d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
-            hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
-          }
-          if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
-            const double* L = ar ? nullptr : J1n;
-            d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
-            hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
-          }
         }
-        if (!ar && !ac) d += si.pts[I][t];  // unary obstacle factor at state i
-        for (int jj = 0; jj < I; jj++) {
-          const GpCoef cf = P.coef[jj];
-          const double w1r = ar ? cf.l12 : cf.l11, w1c = ac ? cf.l12 : cf.l11;
-          const double w2r = ar ? cf.p12 : cf.p11, w2c = ac ? cf.p12 : cf.p11;
-          if (lie) {
-            // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
-            if (has_prev) {
-              const double* pt = si.pts[jj];
-              const double* M = pt + RECP;
-              d += hint_quad(pt, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
-              hl += hint_quad(pt, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
-            }
-            if (has_next) {
-              const double* pt = sn.pts[jj];
-              const double* M = pt + RECP;
-              d += hint_quad(pt, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
-              hr += hint_quad(pt, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
-            }
-            continue;
-          }
-          if (has_prev) {
-            const double Gp = si.pts[jj][t];
-            d = fma(w2r * w2c, Gp, d);
-            hl = fma(w2r * w1c, Gp, hl);  // rows: state i (second), cols: state i-1 (first)
-          }
-          if (has_next) {
-            const double Gn = sn.pts[jj][t];
-            d = fma(w1r * w1c, Gn, d);
-            hr = fma(w1r * w2c, Gn, hr);  // rows: state i (first), cols: state i+1 (second)
-          }
+      } else {
+        // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
+        const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
+        if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
+          const double* L = ar ? nullptr : J3i;
+          d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
+          if (want_c) hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
+        }
+        if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
+          const double* L = ar ? nullptr : J1n;
+          d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
+          if (want_c) hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
         }
       }
-      S.r[k] = d;
-      Cr.r[k] = hr;
-      Cl.r[k] = hl;
+      if (!ar && !ac) d += si.pt(I)[tri[k]];  // unary obstacle factor at state i
+      dk[k] = d;
+      hrk[k] = hr;
+      hlk[k] = hl;
+    }
+    // interpolated obstacle factors: interval i (state i second) and interval i+1 (state i first)
+    for (int jj = 0; jj < I; jj++) {
+      const GpCoef cf = P.coef[jj];
+      const double w1c = ac ? cf.l12 : cf.l11, w2c = ac ? cf.p12 : cf.p11;
+      const double* pp_ = si.pt(jj);
+      const double* pn_ = sn.pt(jj);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (!valid[k]) continue;
+        const int ar = a_row[k], kr = k_row[k];
+        const double w1r = ar ? cf.l12 : cf.l11, w2r = ar ? cf.p12 : cf.p11;
+        if (lie) {
+          // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
+          if (has_prev) {
+            const double* M = pp_ + RECP;
+            dk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
+            if (want_c) hlk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
+          }
+          if (has_next) {
+            const double* M = pn_ + RECP;
+            dk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
+            if (want_c) hrk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
+          }
+          continue;
+        }
+        const int t = tri[k];
+        if (has_prev) {
+          const double Gp = pp_[t];
+          dk[k] = fma(w2r * w2c, Gp, dk[k]);
+          if (want_c) hlk[k] = fma(w2r * w1c, Gp, hlk[k]);  // rows: state i (second), cols: state i-1 (first)
+        }
+        if (has_next) {
+          const double Gn = pn_[t];
+          dk[k] = fma(w1r * w1c, Gn, dk[k]);
+          if (want_c) hrk[k] = fma(w1r * w2c, Gn, hrk[k]);  // rows: state i (first), cols: state i+1 (second)
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      S.r[k] = dk[k];
+      Cr.r[k] = hrk[k];
+      Cl.r[k] = hlk[k];
     }
     // this block's share of the graph error: unary point of state i, the interpolated points and the
     // GP prior of the interval ending at i, plus (below) the prior / limit / dynamics terms of state i
     double err_acc = 0.0;
-    if (lane <= I && (lane == I || has_prev)) err_acc = si.pts[lane][NG + D];
-    if (lane == 63 && has_prev) err_acc += si.gp[n];
+    if (lane <= I && (lane == I || has_prev)) err_acc = si.pt(lane)[NG + D];
+    if (lane == 63 && has_prev) err_acc += si.gpr()[n];
     // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -243,32 +302,32 @@ struct Assembler {
         err_acc += ee;
       }
       if (on_rhs) {
-        if (!ar) gg += si.pts[I][NG + kr];
+        if (!ar) gg += si.pt(I)[NG + kr];
         for (int jj = 0; jj < I; jj++) {
           const GpCoef cf = P.coef[jj];
           if (lie) {
-            if (has_prev) gg += hint_vec(si.pts[jj], si.pts[jj] + RECP + (ar ? 27 : 18), ar ? cf.p12 : cf.p11, kr);
-            if (has_next) gg += hint_vec(sn.pts[jj], sn.pts[jj] + RECP + (ar ? 9 : 0), ar ? cf.l12 : cf.l11, kr);
+            if (has_prev) gg += hint_vec(si.pt(jj), si.pt(jj) + RECP + (ar ? 27 : 18), ar ? cf.p12 : cf.p11, kr);
+            if (has_next) gg += hint_vec(sn.pt(jj), sn.pt(jj) + RECP + (ar ? 9 : 0), ar ? cf.l12 : cf.l11, kr);
             continue;
           }
-          if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pts[jj][NG + kr], gg);
-          if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pts[jj][NG + kr], gg);
+          if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pt(jj)[NG + kr], gg);
+          if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pt(jj)[NG + kr], gg);
         }
         if (!lie) {
           // GP prior gradient: + Phi^T u_{i+1} - u_i
-          if (has_next) gg += ar ? (dt * sn.gp[kr] + sn.gp[D + kr]) : sn.gp[kr];
-          if (has_prev) gg -= si.gp[rho];
+          if (has_next) gg += ar ? (dt * sn.gpr()[kr] + sn.gpr()[D + kr]) : sn.gpr()[kr];
+          if (has_prev) gg -= si.gpr()[rho];
         } else {
           // + A_{i+1}^T u_{i+1} + Bm_i^T u_i
           if (has_next) {
-            if (ar) gg += -dt * sn.gp[kr] - sn.gp[D + kr];
-            else if (kr < 3) gg += J1n[0 * 3 + kr] * sn.gp[0] + J1n[1 * 3 + kr] * sn.gp[1] + J1n[2 * 3 + kr] * sn.gp[2];
-            else gg -= sn.gp[kr];
+            if (ar) gg += -dt * sn.gpr()[kr] - sn.gpr()[D + kr];
+            else if (kr < 3) gg += J1n[0 * 3 + kr] * sn.gpr()[0] + J1n[1 * 3 + kr] * sn.gpr()[1] + J1n[2 * 3 + kr] * sn.gpr()[2];
+            else gg -= sn.gpr()[kr];
           }
           if (has_prev) {
-            if (ar) gg += si.gp[D + kr];
-            else if (kr < 3) gg += J3i[0 * 3 + kr] * si.gp[0] + J3i[1 * 3 + kr] * si.gp[1] + J3i[2 * 3 + kr] * si.gp[2];
-            else gg += si.gp[kr];
+            if (ar) gg += si.gpr()[D + kr];
+            else if (kr < 3) gg += J3i[0 * 3 + kr] * si.gpr()[0] + J3i[1 * 3 + kr] * si.gpr()[1] + J3i[2 * 3 + kr] * si.gpr()[2];
+            else gg += si.gpr()[kr];
           }
         }
         S.r[k] = -gg;

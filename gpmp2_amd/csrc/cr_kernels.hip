@@ -103,14 +103,30 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
   return ok;
 }
 
+// Diagnostic build only (-DG2_STAMPS): s_memtime stamps of one workgroup's phases, written to a
+// buffer nothing else reads (cdna_hip_programming.md section 7 "In-kernel stamps").
+#ifdef G2_STAMPS
+#define G2_STAMP(k)                                                          \
+  do {                                                                       \
+    if (tid == 0 && (k) < 64) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define G2_STAMP(k) do {} while (0)
+#endif
+#ifdef G2_STAMPS
+#define G2_ASTAMP(k) do { if (i == 1 && lane == 0) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G2_ASTAMP(k) do {} while (0)
+#endif
+
 // =============================================================================== assemble
-template <int D>
+template <int D, bool LIE>
 __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                   const double* __restrict__ traj, int bufsel,
                                                   double* __restrict__ tiles,
                                                   const int* __restrict__ active) {
   constexpr int n = 2 * D;
-  using Asm = Assembler<D>;
+  using Asm = Assembler<D, LIE>;
   const PlanParams& P = *pp;
   const int N = P.N;
   const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
@@ -118,16 +134,20 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
   // Dogleg retries (phase 1: same linearization, smaller trust region) need no new factorisation
   if (P.opt_type == GPMP2MI_OPT_DOGLEG && active && pb.phase[b] != 0) return;
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  __shared__ typename Asm::Slot slots[2];
+  extern __shared__ __attribute__((aligned(16))) double asm_smem[];
   const double* rec = rec_of(pb, pb.which[b], bufsel);
   const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
-  as.stage(i, slots[0]);
-  as.stage(i + 1, slots[1]);
+  G2_ASTAMP(0);
+  const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
+  as.stage2(i, slot0, slot1);
   __syncthreads();
+  G2_ASTAMP(1);
   const bool odd = (i & 1) != 0;
   Tile S, Cl, Cr;
-  double err_acc = as.build_tiles(i, slots[0], slots[1], traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr);
+  double err_acc = as.build_tiles(i, slot0, slot1, traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr,
+                                  odd || P.opt_type == GPMP2MI_OPT_DOGLEG);
+  G2_ASTAMP(2);
   err_acc = wave_sum(err_acc);
   if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
   // gradient g_i (the rhs column holds -g_i), kept for the step-control scalars of LM / Dogleg
@@ -154,21 +174,28 @@ __global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ 
     Tile V;
 #pragma unroll
     for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+    G2_ASTAMP(3);
     const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
+    G2_ASTAMP(4);
     double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
     tile_store(f, Cl, lane);
     tile_store(f + TILE_DBL, Cr, lane);
     tile_store(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
+    G2_ASTAMP(5);
   }
 }
 
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
-  case DD: k_assemble<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active); break;
+  case DD:                                                                                              \
+    if (hp.lie) k_assemble<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active); \
+    else k_assemble<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active);       \
+    break;
     G2_ASM_CASE(1) G2_ASM_CASE(2) G2_ASM_CASE(3) G2_ASM_CASE(4) G2_ASM_CASE(5) G2_ASM_CASE(6) G2_ASM_CASE(7)
 #undef G2_ASM_CASE
     default:
@@ -240,16 +267,7 @@ __device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, c
 #endif
 constexpr int CR_WAVES = G2_CR_WAVES;
 
-// Diagnostic build only (-DG2_STAMPS): s_memtime stamps of one workgroup's phases, written to a
-// buffer nothing else reads (cdna_hip_programming.md section 7 "In-kernel stamps").
-#ifdef G2_STAMPS
-#define G2_STAMP(k)                                                          \
-  do {                                                                       \
-    if (tid == 0 && (k) < 64) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define G2_STAMP(k) do {} while (0)
-#endif
+
 
 // Forward elimination (levels h >= 2; level 1 was done by k_assemble) of one trajectory's system.
 // All CR_WAVES wavefronts of the workgroup take part; returns false (per wavefront) on a bad pivot.

@@ -2,9 +2,20 @@
 // geometric sphere Jacobians.  Everything is fp64; dof-dependent loops are fully unrolled on the
 // template parameters so that per-lane arrays stay in VGPRs (no runtime-indexed private arrays).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace g2 {
+
+// compile-time loop: f(std::integral_constant<int, I0>{}), ..., f(std::integral_constant<int, I1 - 1>{})
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Signed distance lookup.  Arithmetic follows the reference term by term
@@ -36,9 +47,10 @@ __device__ __forceinline__ bool sdf3_lookup(const SdfDev& s, double px, double p
                        wr0 * wz1 * (v011 - v001) + wr1 * wz1 * (v111 - v101);
   const double g_z = wr0 * wc0 * (v001 - v000) + wr1 * wc0 * (v101 - v100) +
                      wr0 * wc1 * (v011 - v010) + wr1 * wc1 * (v111 - v110);
-  gx = g_col / s.cell;
-  gy = g_row / s.cell;
-  gz = g_z / s.cell;
+  // (g_idx / cell_size of SignedDistanceField.h:97 as a multiplication by the stored reciprocal: <= 1 ulp)
+  gx = g_col * s.inv_cell;
+  gy = g_row * s.inv_cell;
+  gz = g_z * s.inv_cell;
   return true;
 }
 
@@ -55,8 +67,8 @@ __device__ __forceinline__ bool sdf2_lookup(const SdfDev& s, double px, double p
          (hr - row) * (col - lc) * v01 + (row - lr) * (col - lc) * v11;
   const double g_row = (hc - col) * (v10 - v00) + (col - lc) * (v11 - v01);
   const double g_col = (hr - row) * (v01 - v00) + (row - lr) * (v11 - v10);
-  gx = g_col / s.cell;
-  gy = g_row / s.cell;
+  gx = g_col * s.inv_cell;
+  gy = g_row * s.inv_cell;
   return true;
 }
 
@@ -142,9 +154,15 @@ struct Kin {
   static constexpr int NLINKS = (KIND == GPMP2MI_ROBOT_ARM) ? AD
                                 : (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? AD + 1 : 1;
 
-  template <class F>
-  __device__ __forceinline__ static void for_each_sphere(const RobotDev& R, const double (&q)[DOF],
-                                                         F&& f) {
+  // Visitor over the body spheres (sorted by link):
+  //   pre(s, p) -> bool      : called with the sphere centre; return true if the Jacobian is wanted
+  //   post(s, p, J, nc)      : J[k] = d p / d q_k for k < nc (compile-time integral_constant nc),
+  //                            zero for k >= nc -- spheres on link j only depend on the first joints
+  // sub / nsub: visit only the spheres s with s % nsub == sub (lane-split kernels); nsub a power of 2.
+  template <class Pre, class Post>
+  __device__ __forceinline__ static void visit_spheres(const RobotDev& R, const double (&q)[DOF], Pre&& pre,
+                                                       Post&& post, int sub = 0, int nsub = 1) {
+    const int smask = nsub - 1;
     double J[DOF][3];
 #pragma unroll
     for (int k = 0; k < DOF; k++) J[k][0] = J[k][1] = J[k][2] = 0.0;
@@ -154,8 +172,9 @@ struct Kin {
       J[0][0] = 1.0;
       J[1][1] = 1.0;
       for (int s = 0; s < R.nr_spheres; s++) {
+        if ((s & smask) != sub) continue;
         double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
-        f(s, p, J, 2);
+        if (pre(s, p)) post(s, p, J, std::integral_constant<int, 2>{});
       }
       return;
     } else {
@@ -171,19 +190,21 @@ struct Kin {
         Fr.t[0] = q[0]; Fr.t[1] = q[1]; Fr.t[2] = 0;
         vt[0] = q[0]; vt[1] = q[1];
         const double bx[3] = {c, s, 0}, by[3] = {-s, c, 0};
+#pragma unroll
+        for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
         // link 0 = vehicle base
         for (int s0 = R.link_first[0]; s0 < R.link_first[1]; s0++) {
+          if ((s0 & smask) != sub) continue;
           double p[3];
 #pragma unroll
           for (int i = 0; i < 3; i++)
             p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s0] + Fr.c1[i] * R.sph_c[3 * s0 + 1] +
                    Fr.c2[i] * R.sph_c[3 * s0 + 2];
-#pragma unroll
-          for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
+          if (!pre(s0, p)) continue;
           J[2][0] = -(p[1] - vt[1]);  // z x (p - t_veh)
           J[2][1] = (p[0] - vt[0]);
           J[2][2] = 0.0;
-          f(s0, p, J, 3);
+          post(s0, p, J, std::integral_constant<int, 3>{});
         }
         if constexpr (AD > 0) {
           // arm base = veh * base_T_arm  (computeBaseTransPose3, mobileBaseUtils.cpp:34-48)
@@ -198,29 +219,29 @@ struct Kin {
             N.t[i] = Fr.t[i] + Fr.c0[i] * B.t[0] + Fr.c1[i] * B.t[1] + Fr.c2[i] * B.t[2];
           }
           Fr = N;
-#pragma unroll
-          for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
         }
       } else {
         frame_from_3x4(R.base, Fr);
       }
       if constexpr (AD > 0) {
         double zax[AD][3], org[AD][3];
-#pragma unroll
-        for (int j = 0; j < AD; j++) {
+        static_for<0, AD>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
 #pragma unroll
           for (int i = 0; i < 3; i++) {
             zax[j][i] = Fr.c2[i];
             org[j][i] = Fr.t[i];
           }
           dh_advance(Fr, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
-          const int link = (BASE == 3) ? j + 1 : j;
+          constexpr int link = (BASE == 3) ? j + 1 : j;
           for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) {
+            if ((s & smask) != sub) continue;
             double p[3];
 #pragma unroll
             for (int i = 0; i < 3; i++)
               p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s] + Fr.c1[i] * R.sph_c[3 * s + 1] +
                      Fr.c2[i] * R.sph_c[3 * s + 2];
+            if (!pre(s, p)) continue;
             if constexpr (BASE == 3) {
               J[2][0] = -(p[1] - vt[1]);
               J[2][1] = (p[0] - vt[0]);
@@ -233,11 +254,20 @@ struct Kin {
               J[BASE + k][1] = zax[k][2] * rx - zax[k][0] * rz;
               J[BASE + k][2] = zax[k][0] * ry - zax[k][1] * rx;
             }
-            f(s, p, J, BASE + j + 1);
+            post(s, p, J, std::integral_constant<int, BASE + j + 1>{});
           }
-        }
+        });
       }
     }
+  }
+
+  // simple form: f(sorted_index, p[3], Jcol[DOF][3], ncols) for every sphere
+  template <class F>
+  __device__ __forceinline__ static void for_each_sphere(const RobotDev& R, const double (&q)[DOF], F&& f,
+                                                         int sub = 0, int nsub = 1) {
+    visit_spheres(R, q, [](int, const double (&)[3]) { return true; },
+                  [&](int s, const double (&p)[3], const double (&J)[DOF][3], auto nc) { f(s, p, J, (int)decltype(nc)::value); },
+                  sub, nsub);
   }
 };
 

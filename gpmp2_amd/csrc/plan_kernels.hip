@@ -83,23 +83,29 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
 
   if (!(P.obs_skip_first && p == 0)) {
     const double eps = P.eps;
-    K::for_each_sphere(R, q, [&](int s, const double (&pt)[3], const double (&Jc)[D][3], int) {
-      double hx, hy, hz;
-      const double r = hinge_obstacle<SDIM>(sdf, pt[0], pt[1], pt[2], R.sph_r[s] + eps, hx, hy, hz);
-      if (hx == 0.0 && hy == 0.0 && hz == 0.0 && r == 0.0) return;  // inactive hinge: zero row
-      double Jr[D];
+    double hx, hy, hz, r;
+    K::visit_spheres(
+        R, q,
+        [&](int s, const double (&pt)[3]) {
+          r = hinge_obstacle<SDIM>(sdf, pt[0], pt[1], pt[2], R.sph_r[s] + eps, hx, hy, hz);
+          // inactive hinge (or out of the field): zero residual row, nothing to accumulate --
+          // and the sphere's Jacobian is never formed
+          return !(hx == 0.0 && hy == 0.0 && hz == 0.0 && r == 0.0);
+        },
+        [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) {
+          constexpr int NC = decltype(nc)::value;  // columns >= NC of this sphere's Jacobian are zero
+          double Jr[NC];
 #pragma unroll
-      for (int k = 0; k < D; k++)
-        Jr[k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
-      e += r * r;
-      int t = 0;
+          for (int k = 0; k < NC; k++)
+            Jr[k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
+          e += r * r;
 #pragma unroll
-      for (int k = 0; k < D; k++) {
-        gv[k] += Jr[k] * r;
+          for (int k = 0; k < NC; k++) {
+            gv[k] += Jr[k] * r;
 #pragma unroll
-        for (int k2 = k; k2 < D; k2++) G[t++] += Jr[k] * Jr[k2];
-      }
-    });
+            for (int k2 = k; k2 < NC; k2++) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
+          }
+        });
   }
   const double w = P.obs_w;
   double* rb = rec + (size_t)b * P.REC * P.Ppad + p;
@@ -180,6 +186,9 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
                      const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
                      hipStream_t st) {
+  // One lane per evaluation point.  (A 4-lanes-per-point variant that splits the body spheres was
+  // measured and rejected: the per-lane cost is dominated by the kinematic chain, which every lane
+  // would repeat -- 44 us vs 26 us at B = 64, no gain even at B = 1)
   const dim3 grid(hp.B * (hp.Ppad / 64)), block(64);
   if (sdf.dim == 3) {
     G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
@@ -382,24 +391,24 @@ int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool in
 }
 
 // =============================================================================== export H, g
-template <int D>
+template <int D, bool LIE>
 __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                           const double* __restrict__ traj, int bufsel,
                                                           double* __restrict__ Hd, double* __restrict__ Ho,
                                                           double* __restrict__ gout) {
   constexpr int n = 2 * D;
-  using Asm = Assembler<D>;
+  using Asm = Assembler<D, LIE>;
   const PlanParams& P = *pp;
   const int N = P.N;
   const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  __shared__ typename Asm::Slot slots[2];
+  extern __shared__ __attribute__((aligned(16))) double asm_smem[];
   Asm as(P, pb, rec_of(pb, pb.which[b], bufsel), gpu_of(pb, pb.which[b], bufsel), b, lane);
-  as.stage(i, slots[0]);
-  as.stage(i + 1, slots[1]);
+  const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
+  as.stage2(i, slot0, slot1);
   __syncthreads();
   Tile S, Cl, Cr;
-  as.build_tiles(i, slots[0], slots[1], traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr);
+  as.build_tiles(i, slot0, slot1, traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr, true);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const int rho = g + 4 * k;
@@ -415,9 +424,13 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                             double* Hd, double* Ho, double* g, hipStream_t st) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
   switch (hp.D) {
 #define G2_EXP_CASE(DD) \
-  case DD: k_export_normal_eq<DD><<<grid, block, 0, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g); break;
+  case DD:                                                                                          \
+    if (hp.lie) k_export_normal_eq<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g); \
+    else k_export_normal_eq<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g);       \
+    break;
     G2_EXP_CASE(1) G2_EXP_CASE(2) G2_EXP_CASE(3) G2_EXP_CASE(4) G2_EXP_CASE(5) G2_EXP_CASE(6) G2_EXP_CASE(7)
 #undef G2_EXP_CASE
     default:

@@ -3,22 +3,13 @@
 #pragma once
 #include <type_traits>
 
-#include "common.h"
+#include "device_math.h"
 
 namespace g2 {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------------------------
-// compile-time loop
-template <int I0, int I1, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I0 < I1) {
-    f(std::integral_constant<int, I0>{});
-    static_for<I0 + 1, I1>(f);
-  }
-}
-
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
