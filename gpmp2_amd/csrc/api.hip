@@ -220,10 +220,13 @@ struct gpmp2mi_plan {
   KernelTimer timer;
   bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
   int n_active_len = 0;
+  std::vector<int> h_xp_n;   // host mirror of the extra-prior counts
   bool problem_set = false;
   bool optimized = false;
   size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
 };
+
+static int plan_run(gpmp2mi_plan* p, hipStream_t st);
 
 template <class T>
 static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
@@ -711,6 +714,17 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.hgpart, (size_t)B * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
+  G2_TRY(plan_alloc(p.get(), &pb.xp_n, B));
+  G2_TRY(plan_alloc(p.get(), &pb.xp_state, (size_t)B * XP_MAX));
+  G2_TRY(plan_alloc(p.get(), &pb.xp_has_vel, (size_t)B * XP_MAX));
+  G2_TRY(plan_alloc(p.get(), &pb.xp_target, (size_t)B * XP_MAX * P.n));
+  G2_TRY(plan_alloc(p.get(), &pb.xp_info, (size_t)B * XP_MAX * 2 * D * D));
+  G2_TRY(plan_alloc(p.get(), &pb.goal_on, B));
+  {
+    std::vector<int> ones(B, 1);
+    G2_HIP(hipMemcpy(pb.goal_on, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
+    p->h_xp_n.assign(B, 0);
+  }
   G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * P.GPREC * P.Npad));
@@ -784,10 +798,15 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   G2_CHECK(p, GPMP2MI_ERR_INVALID, "null plan");
   G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
   hipStream_t st = (hipStream_t)stream;
+  G2_HIP(hipMemcpyAsync(p->pb.cur, p->pb.init, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
+  return plan_run(p, st);
+}
+
+// the optimizer driver: `cur` holds the starting values
+static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
   const PlanParams& P = p->hp;
   PlanBuffers& pb = p->pb;
   p->timer.reset();
-  G2_HIP(hipMemcpyAsync(pb.cur, pb.init, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
   G2_TRY(launch_plan_reset(P, pb, st));
   const int iter_cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
   if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn) {
@@ -907,6 +926,99 @@ int gpmp2mi_plan_linearize(gpmp2mi_plan* p, const double* traj, double* Hdiag, d
   G2_TRY(dg.download(g));
   G2_TRY(de.download(err));
   return GPMP2MI_OK;
+}
+
+// -------------------------------------------------------------------------------------------- replanning
+static int plan_add_prior(gpmp2mi_plan* p, int b, int state, const double* conf, const double* Wc, const double* vel,
+                          const double* Wv) {
+  G2_CHECK(p && conf && Wc, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(b >= 0 && b < p->hp.B && state >= 0 && state <= p->hp.N, GPMP2MI_ERR_INVALID, "index out of range");
+  G2_CHECK(p->h_xp_n[b] < XP_MAX, GPMP2MI_ERR_UNSUPPORTED, "too many state priors on this trajectory");
+  const int D = p->hp.D, n = p->hp.n, e = p->h_xp_n[b];
+  const size_t xe = (size_t)b * XP_MAX + e;
+  std::vector<double> tg(n, 0.0), info(2 * D * D, 0.0);
+  std::copy(conf, conf + D, tg.begin());
+  std::copy(Wc, Wc + D * D, info.begin());
+  const int has_vel = (vel && Wv) ? 1 : 0;
+  if (has_vel) {
+    std::copy(vel, vel + D, tg.begin() + D);
+    std::copy(Wv, Wv + D * D, info.begin() + D * D);
+  }
+  G2_HIP(hipMemcpy(p->pb.xp_target + xe * n, tg.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  G2_HIP(hipMemcpy(p->pb.xp_info + xe * 2 * D * D, info.data(), info.size() * sizeof(double), hipMemcpyHostToDevice));
+  G2_HIP(hipMemcpy(p->pb.xp_state + xe, &state, sizeof(int), hipMemcpyHostToDevice));
+  G2_HIP(hipMemcpy(p->pb.xp_has_vel + xe, &has_vel, sizeof(int), hipMemcpyHostToDevice));
+  p->h_xp_n[b] = e + 1;
+  G2_HIP(hipMemcpy(p->pb.xp_n + b, &p->h_xp_n[b], sizeof(int), hipMemcpyHostToDevice));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_fix_state(gpmp2mi_plan* p, int b, int state_idx, const double* conf, const double* vel) {
+  G2_CHECK(p && conf && vel, GPMP2MI_ERR_INVALID, "null argument");
+  const int D = p->hp.D;
+  std::vector<double> Wc(D * D, 0.0), Wv(D * D, 0.0);
+  for (int k = 0; k < D; k++) {
+    Wc[k * D + k] = p->hp.conf_prior_w;
+    Wv[k * D + k] = p->hp.vel_prior_w;
+  }
+  return plan_add_prior(p, b, state_idx, conf, Wc.data(), vel, Wv.data());
+}
+
+int gpmp2mi_plan_add_state_estimate(gpmp2mi_plan* p, int b, int state_idx, const double* conf, const double* conf_cov,
+                                    const double* vel, const double* vel_cov) {
+  G2_CHECK(p && conf && conf_cov, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK((vel == nullptr) == (vel_cov == nullptr), GPMP2MI_ERR_INVALID, "pass vel and vel_cov together");
+  const int D = p->hp.D;
+  std::vector<double> Wc(D * D), Wv(D * D);
+  G2_CHECK(invert_small(D, conf_cov, Wc.data()), GPMP2MI_ERR_INVALID, "pose covariance is singular");
+  if (vel) G2_CHECK(invert_small(D, vel_cov, Wv.data()), GPMP2MI_ERR_INVALID, "velocity covariance is singular");
+  return plan_add_prior(p, b, state_idx, conf, Wc.data(), vel, vel ? Wv.data() : nullptr);
+}
+
+int gpmp2mi_plan_change_goal(gpmp2mi_plan* p, int b, const double* goal_conf, const double* goal_vel) {
+  G2_CHECK(p && goal_conf && goal_vel && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  const int D = p->hp.D, one = 1;
+  G2_HIP(hipMemcpy(p->pb.end_conf + (size_t)b * D, goal_conf, D * sizeof(double), hipMemcpyHostToDevice));
+  G2_HIP(hipMemcpy(p->pb.end_vel + (size_t)b * D, goal_vel, D * sizeof(double), hipMemcpyHostToDevice));
+  G2_HIP(hipMemcpy(p->pb.goal_on + b, &one, sizeof(int), hipMemcpyHostToDevice));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_remove_goal(gpmp2mi_plan* p, int b) {
+  G2_CHECK(p && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  const int zero = 0;
+  G2_HIP(hipMemcpy(p->pb.goal_on + b, &zero, sizeof(int), hipMemcpyHostToDevice));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_clear_state_priors(gpmp2mi_plan* p, int b) {
+  G2_CHECK(p && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  p->h_xp_n[b] = 0;
+  G2_HIP(hipMemcpy(p->pb.xp_n + b, &p->h_xp_n[b], sizeof(int), hipMemcpyHostToDevice));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream) {
+  G2_CHECK(p && iterations > 0, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
+  G2_CHECK(iterations <= p->hp.max_iter, GPMP2MI_ERR_INVALID, "iterations exceeds max_iter");
+  hipStream_t st = (hipStream_t)stream;
+  // warm start: the previous estimate becomes the initial values of this run
+  const double* from = p->optimized ? p->pb.result : p->pb.init;
+  G2_HIP(hipMemcpyAsync(p->pb.cur, from, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
+  // temporarily switch the resident parameters to `iterations` fixed Gauss-Newton steps
+  PlanParams saved = p->hp;
+  p->hp.opt_type = GPMP2MI_OPT_GAUSS_NEWTON;
+  p->hp.fixed_iters = iterations;
+  G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));
+  const bool gg = p->generic_gn;
+  p->generic_gn = false;
+  const int rc = plan_run(p, st);
+  p->generic_gn = gg;
+  p->hp = saved;
+  G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));
+  G2_HIP(hipStreamSynchronize(st));
+  return rc;
 }
 
 int gpmp2mi_batch_optimize(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, const gpmp2mi_settings* s,

@@ -244,6 +244,17 @@ struct Assembler {
         }
       }
     }
+    const int nxp = pb.xp_n[b];
+    for (int e = 0; e < nxp; e++) {
+      const size_t xe = (size_t)b * XP_MAX + e;
+      if (pb.xp_state[xe] != i) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // the diagonal entries are added with the other diagonal terms below
+        if (!valid[k] || a_row[k] != ac || (ac && !pb.xp_has_vel[xe]) || (g + 4 * k) == c) continue;
+        dk[k] += pb.xp_info[(xe * 2 + ac) * D * D + (size_t)k_row[k] * D + kc];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       S.r[k] = dk[k];
@@ -265,13 +276,13 @@ struct Assembler {
       const int ar = a_row[k], kr = k_row[k];
       double dd = 0.0, gg = 0.0, ee = 0.0;
       const double zz = z[rho];
-      if (i == 0 || i == N) {  // PriorFactor on x_0, v_0, x_N, v_N  (BatchTrajOptimizer-inl.h:41-48)
+      if (i == 0 || (i == N && pb.goal_on[b])) {  // PriorFactor on x_0, v_0, x_N, v_N  (BatchTrajOptimizer-inl.h:41-48)
         const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
         tg += (size_t)b * D;
         const double w = ar ? P.vel_prior_w : P.conf_prior_w;
         double dz = zz - tg[kr];
         if (lie && !ar && kr < 3) {
-          // gtsam 4.0 PriorFactor<Pose2Vector>: error = -Local(x, prior), H = I (see oracle_core.cpp)
+          // gtsam 4.0 PriorFactor<Pose2Vector>: error = -Local(x, prior), H = I
           const P2 bt = pose2_between(P2{z[0], z[1], z[2]}, P2{tg[0], tg[1], tg[2]});
           dz = -(kr == 0 ? bt.x : kr == 1 ? bt.y : bt.th);
         }
@@ -296,6 +307,27 @@ struct Assembler {
         dd += P.vdyn_w;
         gg += P.vdyn_w * zz;
         ee += P.vdyn_w * zz * zz;
+      }
+      // extra per-state priors of the replanner (fixConfigAndVel / addStateEstimate,
+      // planner/ISAM2TrajOptimizer-inl.h:159-195): full information matrices
+      for (int e = 0; e < nxp; e++) {
+        const size_t xe = (size_t)b * XP_MAX + e;
+        if (pb.xp_state[xe] != i || (ar && !pb.xp_has_vel[xe])) continue;
+        const double* Wm = pb.xp_info + (xe * 2 + ar) * D * D + (size_t)kr * D;  // row kr
+        const double* tg = pb.xp_target + xe * n + ar * D;
+        double wr = 0.0, rk = 0.0;
+        for (int cc = 0; cc < D; cc++) {
+          double rc = z[ar * D + cc] - tg[cc];
+          if (lie && !ar && cc < 3) {
+            const P2 bt = pose2_between(P2{z[0], z[1], z[2]}, P2{tg[0], tg[1], tg[2]});
+            rc = -(cc == 0 ? bt.x : cc == 1 ? bt.y : bt.th);
+          }
+          wr = fma(Wm[cc], rc, wr);
+          if (cc == kr) rk = rc;
+        }
+        dd += Wm[kr];
+        gg += wr;
+        ee += wr * rk;
       }
       if (on_diag) {
         S.r[k] += dd;

@@ -6,7 +6,8 @@
 namespace g2 {
 
 constexpr int MAXI = 16;   // max obs_check_inter
-constexpr int TILE = 16;   // block-tridiagonal tile edge (n = 2*dof <= 16 in the MFMA solver)
+constexpr int TILE = 16;
+constexpr int XP_MAX = GPMP2MI_MAX_STATE_PRIORS;  // extra per-state priors per trajectory (replanning)   // block-tridiagonal tile edge (n = 2*dof <= 16 in the MFMA solver)
 
 // Uniform parameters of a plan; lives in HBM, read through scalar loads.
 struct PlanParams {
@@ -52,6 +53,13 @@ struct PlanBuffers {
   double* htiles;          // [B][N+1][2][256] un-eliminated D_i and H_{i,i+1} (Dogleg: g^T H g)
   double* hgpart;          // [B][Npad] per-block share of g^T H g
   double* scal;            // [B][16] per-trajectory scalars of the current trial step (see SC_*)
+  // extra priors (gpmp2mi_plan_fix_state / add_state_estimate) and goal switch (remove_goal)
+  int* xp_n;               // [B] number of extra priors
+  int* xp_state;           // [B][XP_MAX] state index
+  int* xp_has_vel;         // [B][XP_MAX] 1 if the entry also constrains the velocity
+  double* xp_target;       // [B][XP_MAX][2D] conf, vel
+  double* xp_info;         // [B][XP_MAX][2][D*D] information matrices (conf, vel)
+  int* goal_on;            // [B] 0 after removeGoalConfigAndVel
   int* which;              // [B] record buffer (0: rec/gpu, 1: rec2/gpu2) holding the linearization at `cur`
   // per-trajectory scalars
   double* cur_err;         // error at `cur`

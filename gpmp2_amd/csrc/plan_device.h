@@ -19,7 +19,7 @@ __device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuff
     const int i = idx / n, rho = idx - i * n;
     const int a = rho >= D, k = rho - a * D;
     const double z = tr[idx];
-    if (i == 0 || i == N) {
+    if (i == 0 || (i == N && pb.goal_on[b])) {
       const double* tg = (i == 0) ? (a ? pb.start_vel : pb.start_conf) : (a ? pb.end_vel : pb.end_conf);
       tg += (size_t)b * D;
       double d = z - tg[k];
@@ -29,6 +29,24 @@ __device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuff
         d = -(k == 0 ? bt.x : k == 1 ? bt.y : bt.th);
       }
       acc += (a ? P.vel_prior_w : P.conf_prior_w) * d * d;
+    }
+    for (int e = 0; e < pb.xp_n[b]; e++) {  // replanner state priors: r^T W r, row k's share
+      const size_t xe = (size_t)b * XP_MAX + e;
+      if (pb.xp_state[xe] != i || (a && !pb.xp_has_vel[xe])) continue;
+      const double* Wm = pb.xp_info + (xe * 2 + a) * D * D + (size_t)k * D;
+      const double* tg = pb.xp_target + xe * n + a * D;
+      const double* zs = tr + (size_t)i * n;
+      double wr = 0.0, rk = 0.0;
+      for (int cc = 0; cc < D; cc++) {
+        double rc = zs[a * D + cc] - tg[cc];
+        if (P.lie && !a && cc < 3) {
+          const P2 bt = pose2_between(P2{zs[0], zs[1], zs[2]}, P2{tg[0], tg[1], tg[2]});
+          rc = -(cc == 0 ? bt.x : cc == 1 ? bt.y : bt.th);
+        }
+        wr = fma(Wm[cc], rc, wr);
+        if (cc == k) rk = rc;
+      }
+      acc += wr * rk;
     }
     double H;
     if (!a && P.flag_pos_limit && !(P.lie && k < 3)) {

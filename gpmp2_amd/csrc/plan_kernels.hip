@@ -251,7 +251,7 @@ int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t s
 //   LevenbergMarquardtOptimizer::tryLambda  (model fidelity test, lambda *= / /= 10, give up at 1e5)
 //   DoglegOptimizerImpl::Iterate(ONE_STEP_PER_ITERATION)  (gain ratio rho, trust radius update)
 // followed by the do/while of gpmp2::optimize (checkConvergence, max_iter, no-increase rollback).
-// GTSAM semantics restated from upstream -- identical to oracle_core.cpp.
+// GTSAM semantics restated from upstream.
 __global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
   const PlanParams& P = *pp;
   const int b = blockIdx.x, lane = threadIdx.x;

@@ -260,6 +260,31 @@ class Plan:
         self.eng._ck(self.eng.lib.gpmp2mi_plan_linearize(self.h.ptr, dptr(t), dptr(Hd), dptr(Ho), dptr(g), dptr(err)))
         return Hd, Ho, g, err
 
+    # ---- incremental replanning (ISAM2TrajOptimizer's role; see include/gpmp2mi.h)
+    def fix_state(self, b, state_idx, conf, vel):
+        c, v = f64(conf).reshape(self.D), f64(vel).reshape(self.D)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_fix_state(self.h.ptr, int(b), int(state_idx), dptr(c), dptr(v)))
+
+    def add_state_estimate(self, b, state_idx, conf, conf_cov, vel=None, vel_cov=None):
+        c, cc = f64(conf).reshape(self.D), f64(conf_cov).reshape(self.D, self.D)
+        v = None if vel is None else f64(vel).reshape(self.D)
+        vc = None if vel_cov is None else f64(vel_cov).reshape(self.D, self.D)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_add_state_estimate(self.h.ptr, int(b), int(state_idx), dptr(c), dptr(cc),
+                                                                  dptr(v), dptr(vc)))
+
+    def change_goal(self, b, goal_conf, goal_vel):
+        c, v = f64(goal_conf).reshape(self.D), f64(goal_vel).reshape(self.D)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_change_goal(self.h.ptr, int(b), dptr(c), dptr(v)))
+
+    def remove_goal(self, b):
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_remove_goal(self.h.ptr, int(b)))
+
+    def clear_state_priors(self, b):
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_clear_state_priors(self.h.ptr, int(b)))
+
+    def update(self, iterations=1, stream=None):
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_update(self.h.ptr, int(iterations), C.c_void_p(stream or 0)))
+
     def enable_timing(self, on=True):
         self.eng._ck(self.eng.lib.gpmp2mi_plan_enable_timing(self.h.ptr, int(on)))
 

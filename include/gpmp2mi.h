@@ -203,6 +203,30 @@ int gpmp2mi_plan_get_result_dev(gpmp2mi_plan* p, double* traj, int* iters, doubl
 /* device pointer to the resident [B][N+1][2D] result (valid until the plan is destroyed) */
 const double* gpmp2mi_plan_traj_dev(const gpmp2mi_plan* p);
 
+/* ---- incremental replanning ---------------------------------------
+ * The role of gpmp2::ISAM2TrajOptimizer{2DArm,3DArm,Pose2MobileArm...}
+ * (planner/ISAM2TrajOptimizer.h:57-171, planner/ISAM2TrajOptimizer-inl.h:16-195; usage
+ * matlab/WAMReplannerExample.m:102-126) on the same resident plan: the chain graph is re-solved warm
+ * from the current estimate with extra per-state priors.  One gpmp2mi_plan_update(p, 1, ...) is one
+ * relinearise-and-solve Gauss-Newton step of the WHOLE chain -- iSAM2 would relinearise only the
+ * variables whose delta exceeds relinearizeThreshold (1e-3, -inl.h:20-21); exact iSAM2 parity is
+ * unpinned (no reference test exercises it, planner/tests/testISAM2TrajOptimizer.cpp:24-67).
+ * `b` selects the trajectory of the batch; up to GPMP2MI_MAX_STATE_PRIORS priors per trajectory. */
+#define GPMP2MI_MAX_STATE_PRIORS 8
+/* fixConfigAndVel(state_idx, conf, vel): tight priors (conf_prior_model / vel_prior_model)  -inl.h:159-169 */
+int gpmp2mi_plan_fix_state(gpmp2mi_plan* p, int b, int state_idx, const double* conf, const double* vel);
+/* addPoseEstimate / addStateEstimate: Gaussian priors with full covariance [D][D]; vel / vel_cov may be
+ * NULL (pose only)  -inl.h:172-195 */
+int gpmp2mi_plan_add_state_estimate(gpmp2mi_plan* p, int b, int state_idx, const double* conf,
+                                    const double* conf_cov, const double* vel, const double* vel_cov);
+/* changeGoalConfigAndVel / removeGoalConfigAndVel  -inl.h:118-156 */
+int gpmp2mi_plan_change_goal(gpmp2mi_plan* p, int b, const double* goal_conf, const double* goal_vel);
+int gpmp2mi_plan_remove_goal(gpmp2mi_plan* p, int b);
+int gpmp2mi_plan_clear_state_priors(gpmp2mi_plan* p, int b);
+/* update(): `iterations` Gauss-Newton steps warm-started from the current estimate (the result of the
+ * previous optimize / update; the initial values if there is none).  Results via gpmp2mi_plan_get_result. */
+int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream);
+
 /* NonlinearFactorGraph::error(values) of the plan's graph for arbitrary trajectories
  * (host pointers; traj [B][N+1][2D] -> err [B]); uses the plan's start/end priors. */
 int gpmp2mi_plan_graph_error(gpmp2mi_plan* p, const double* traj, double* err);

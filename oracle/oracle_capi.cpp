@@ -352,6 +352,42 @@ int orc_batch_optimize(const void* r, const void* s, const gpmp2mi_settings* set
   return 0;
 }
 
+// batch optimize with the replanner's extra state priors and goal switch (mirrors
+// gpmp2mi_plan_fix_state / add_state_estimate / remove_goal + gpmp2mi_plan_update)
+int orc_batch_optimize_xp(const void* r, const void* s, const gpmp2mi_settings* set, const gpmp2mi_graph_opts* o,
+                          int B, const double* sc, const double* sv, const double* ec, const double* ev,
+                          const double* init, const int* xp_n, const int* xp_state, const int* xp_has_vel,
+                          const double* xp_target, const double* xp_info, const int* goal_on, double* out,
+                          int* iters, double* final_err, int* status) {
+  const int d = set->dof, XP = GPMP2MI_MAX_STATE_PRIORS;
+  const size_t m = (size_t)(set->total_step + 1) * 2 * d;
+  for (int b = 0; b < B; b++) {
+    Problem P = make_problem((const Robot*)r, (const Sdf*)s, set, o, sc + (size_t)b * d, sv + (size_t)b * d,
+                             ec + (size_t)b * d, ev + (size_t)b * d);
+    P.set.goal_on = goal_on ? goal_on[b] != 0 : true;
+    for (int e = 0; xp_n && e < xp_n[b]; e++) {
+      const size_t xe = (size_t)b * XP + e;
+      Settings::StatePrior sp;
+      sp.state = xp_state[xe];
+      sp.has_vel = xp_has_vel[xe] != 0;
+      sp.conf.assign(xp_target + xe * 2 * d, xp_target + xe * 2 * d + d);
+      sp.vel.assign(xp_target + xe * 2 * d + d, xp_target + xe * 2 * d + 2 * d);
+      sp.Wc = Mat(d, d);
+      sp.Wv = Mat(d, d);
+      for (int k = 0; k < d * d; k++) {
+        sp.Wc.a[k] = xp_info[xe * 2 * d * d + k];
+        sp.Wv.a[k] = xp_info[xe * 2 * d * d + d * d + k];
+      }
+      P.set.state_priors.push_back(sp);
+    }
+    OptResult res = optimize(P, init + b * m, out + b * m);
+    if (iters) iters[b] = res.iterations;
+    if (final_err) final_err[b] = res.final_error;
+    if (status) status[b] = res.status;
+  }
+  return 0;
+}
+
 int orc_collision_cost(const void* r, const void* s, int total_step, int B, const double* traj,
                        double* cost) {
   // internal::CollisionCost  planner/BatchTrajOptimizer-inl.h:87-100 (epsilon = 0)

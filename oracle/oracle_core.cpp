@@ -794,7 +794,7 @@ double Problem::linearize(const double* traj, std::vector<LinFactor>* F) const {
     const double* x = traj + (size_t)i * n;
     const double* v = x + d;
     // PriorFactor on start / end  (BatchTrajOptimizer-inl.h:41-48)
-    if (i == 0 || i == N) {
+    if (i == 0 || (i == N && set.goal_on)) {
       const double* pc = (i == 0) ? start_conf.data() : end_conf.data();
       const double* pv = (i == 0) ? start_vel.data() : end_vel.data();
       LinFactor f;
@@ -825,6 +825,33 @@ double Problem::linearize(const double* traj, std::vector<LinFactor>* F) const {
       if (F)
         for (int k = 0; k < d; k++) g.A[(size_t)k * n + d + k] = 1.0 / set.vel_prior_sigma;
       push(std::move(g));
+    }
+    // replanner priors: fixConfigAndVel / addPoseEstimate / addStateEstimate
+    // (planner/ISAM2TrajOptimizer-inl.h:159-195): PriorFactor with a Gaussian (full information) model
+    for (const auto& sp : set.state_priors) {
+      if (sp.state != i) continue;
+      for (int part = 0; part < (sp.has_vel ? 2 : 1); part++) {
+        const Mat Rm = chol_upper(part ? sp.Wv : sp.Wc);
+        std::vector<double> r(d);
+        const double* tg = part ? sp.vel.data() : sp.conf.data();
+        const double* zz = part ? v : x;
+        for (int k = 0; k < d; k++) r[k] = zz[k] - tg[k];
+        if (lie && !part) {
+          const Pose2 b = pose2_between(Pose2{x[0], x[1], x[2]}, Pose2{tg[0], tg[1], tg[2]});
+          r[0] = -b.x; r[1] = -b.y; r[2] = -b.th;
+        }
+        LinFactor f;
+        f.s0 = i; f.ns = 1; f.m = d; f.r.assign(d, 0.0);
+        if (F) f.A.assign((size_t)d * n, 0.0);
+        for (int a = 0; a < d; a++) {
+          double s = 0;
+          for (int k = 0; k < d; k++) s += Rm(a, k) * r[k];
+          f.r[a] = s;
+          if (F)
+            for (int k = 0; k < d; k++) f.A[(size_t)a * n + part * d + k] = Rm(a, k);
+        }
+        push(std::move(f));
+      }
     }
     // joint / velocity limits  (BatchTrajOptimizer-inl.h:50-59)
     if (set.flag_pos_limit) {

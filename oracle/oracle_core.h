@@ -142,6 +142,15 @@ struct Settings {
          lm_lambda_lower = 0, lm_min_model_fidelity = 1e-3;
   double dogleg_delta_initial = 0.2, abs_error_tol = 1e-5, error_tol = 0;
   int fixed_iterations = 0;
+  // replanner state (planner/ISAM2TrajOptimizer-inl.h:118-195)
+  bool goal_on = true;
+  struct StatePrior {
+    int state = 0;
+    bool has_vel = false;
+    std::vector<double> conf, vel;  // targets
+    Mat Wc, Wv;                     // information matrices
+  };
+  std::vector<StatePrior> state_priors;
 };
 
 // one whitened factor touching states [s0, s0 + ns) with m rows: A [m][ns * 2 dof], b [m] = r

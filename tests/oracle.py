@@ -211,6 +211,32 @@ class Oracle:
                                     iptr(status), dptr(trace), int(nthreads))
         return dict(traj=out, iters=iters, final_error=ferr, status=status, error_trace=trace)
 
+    def batch_optimize_xp(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, init, priors, goal_on):
+        """priors: per trajectory a list of dicts(state, conf, Wc, vel=None, Wv=None); goal_on: [B] ints."""
+        s, o, keep = _capi.make_settings(setting)
+        B, sc, sv, ec, ev, t = self._problem_arrays(setting, start_conf, start_vel, end_conf, end_vel, init)
+        D, XP = setting.dof, 8
+        xp_n = np.zeros(B, dtype=np.int32)
+        xp_state, xp_hv = np.zeros((B, XP), dtype=np.int32), np.zeros((B, XP), dtype=np.int32)
+        xp_t, xp_i = np.zeros((B, XP, 2 * D)), np.zeros((B, XP, 2, D, D))
+        for b in range(B):
+            for e, pr in enumerate(priors[b]):
+                xp_state[b, e] = pr["state"]
+                xp_t[b, e, :D] = pr["conf"]
+                xp_i[b, e, 0] = pr["Wc"]
+                if pr.get("vel") is not None:
+                    xp_hv[b, e] = 1
+                    xp_t[b, e, D:] = pr["vel"]
+                    xp_i[b, e, 1] = pr["Wv"]
+            xp_n[b] = len(priors[b])
+        gon = np.ascontiguousarray(goal_on, dtype=np.int32)
+        out = np.zeros_like(t)
+        iters, status, ferr = np.zeros(B, dtype=np.int32), np.zeros(B, dtype=np.int32), np.zeros(B)
+        self.lib.orc_batch_optimize_xp(robot.ptr, sdf.ptr, C.byref(s), C.byref(o), B, dptr(sc), dptr(sv), dptr(ec),
+                                       dptr(ev), dptr(t), iptr(xp_n), iptr(xp_state), iptr(xp_hv), dptr(xp_t),
+                                       dptr(xp_i), iptr(gon), dptr(out), iptr(iters), dptr(ferr), iptr(status))
+        return dict(traj=out, iters=iters, final_error=ferr, status=status)
+
     def collision_cost(self, robot, sdf, total_step, traj):
         t = f64(traj).reshape(-1, total_step + 1, 2 * robot.dof)
         cost = np.zeros(t.shape[0])

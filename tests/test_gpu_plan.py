@@ -402,3 +402,56 @@ def test_pose2_mobile_base_robot(engine, oracle):
         a, b = fa(r, q), fb(ro, q)
         np.testing.assert_allclose(a[0], b[0], atol=1e-9)
         np.testing.assert_allclose(a[1], b[1], atol=1e-9)
+
+
+def test_replanner_fix_state_change_goal_update(engine, oracle):
+    """WAMReplannerExample flow (matlab/WAMReplannerExample.m:102-126): batch solve, then
+    fixConfigAndVel(5, ...), changeGoalConfigAndVel(...), update(); plus addStateEstimate with a full
+    covariance and removeGoalConfigAndVel.  The oracle runs the same warm-started fixed-iteration
+    Gauss-Newton with the same extra priors (exact iSAM2 parity is unpinned, see include/gpmp2mi.h)."""
+    p = problems.wam_restarts(B=2, total_step=10, obs_check_inter=4, sdf="40")
+    r, s, ro, so = _handles(engine, oracle, p)
+    D = 7
+    pl = engine.plan(r, s, p.setting, p.B)
+    pl.set_problem(*_args(p), p.init)
+    pl.optimize()
+    first = pl.result()["traj"]
+    # --- step 1: execute up to state 5, fix it, move the goal of trajectory 0
+    new_goal = np.array([-0.6, 0.94, 0, 1.6, 0, -0.919, 1.55])
+    pl.fix_state(0, 5, first[0, 5, :D], first[0, 5, D:])
+    pl.change_goal(0, new_goal, np.zeros(D))
+    rng = np.random.default_rng(61)
+    A = rng.normal(size=(D, D))
+    cov = 1e-4 * (A @ A.T + D * np.eye(D))
+    est = first[1, 3, :D] + 0.01
+    pl.add_state_estimate(1, 3, est, cov)                      # pose-only estimate on trajectory 1
+    pl.remove_goal(1)
+    pl.update(iterations=2)
+    got = pl.result()
+    st = problems.wam_setting(10, 4, "GN")
+    st.fixed_iterations = 2
+    w = 1.0 / st.conf_prior_sigma ** 2
+    priors = [[dict(state=5, conf=first[0, 5, :D], Wc=w * np.eye(D), vel=first[0, 5, D:], Wv=w * np.eye(D))],
+              [dict(state=3, conf=est, Wc=np.linalg.inv(cov))]]
+    end = p.end_conf.copy()
+    end[0] = new_goal
+    ref = oracle.batch_optimize_xp(ro, so, st, p.start_conf, p.start_vel, end, p.end_vel, first, priors, [1, 0])
+    assert list(got["iters"]) == [2, 2]
+    np.testing.assert_allclose(got["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(got["final_error"], ref["final_error"], rtol=1e-8)
+    # the fixed state stayed put, the new goal is reached, the free end of trajectory 1 moved
+    np.testing.assert_allclose(got["traj"][0, 5, :D], first[0, 5, :D], atol=1e-3)
+    np.testing.assert_allclose(got["traj"][0, -1, :D], new_goal, atol=1e-3)
+    # --- step 2: a second update continues from the new estimate
+    pl.update(iterations=1)
+    again = pl.result()
+    st.fixed_iterations = 1
+    ref2 = oracle.batch_optimize_xp(ro, so, st, p.start_conf, p.start_vel, end, p.end_vel, ref["traj"], priors, [1, 0])
+    np.testing.assert_allclose(again["traj"], ref2["traj"], atol=1e-6)
+    # --- clearing the priors and re-optimising from scratch reproduces the batch answer of the new goal
+    pl.clear_state_priors(0)
+    pl.clear_state_priors(1)
+    pl.change_goal(1, p.end_conf[1], p.end_vel[1])
+    pl.optimize()
+    ref3 = oracle.batch_optimize(ro, so, p.setting, p.start_conf, p.start_vel, end, p.end_vel, p.init)
+    np.testing.assert_allclose(pl.result()["traj"], ref3["traj"], atol=1e-6)
