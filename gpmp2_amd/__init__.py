@@ -9,6 +9,14 @@ from .datasets import (generate2Ddataset, generate3Ddataset, sdf3_zyx, signedDis
 from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pose2MobileArm,  # noqa: F401
                      Pose2MobileArmModel, Pose2MobileBase, Pose2MobileBaseModel, generateArm,
                      generateMobileArm, generatePointRobot, pose3, rot_yaw)
+from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2MobileArm,  # noqa: F401
+                      BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
+                      CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,
+                      ISAM2TrajOptimizer3DArm, ISAM2TrajOptimizerPose2MobileArm, ISAM2TrajOptimizerPose2MobileArm2D,
+                      PlanarSDF, SDFQueryOutOfRange, SignedDistanceField)
 from .settings import TrajOptimizerSetting  # noqa: F401
+from .trajutils import (initArmTrajStraightLine, initPose2TrajStraightLine, initPose2VectorTrajStraightLine,  # noqa: F401
+                        interpolateArmTraj, interpolatePose2MobileArmTraj, interpolatePose2Traj, traj_from_values,
+                        values_from_traj)
 
 __all__ = [n for n in dir() if not n.startswith("_")]

@@ -550,6 +550,34 @@ int gpmp2mi_gp_interpolate(int D, int lie, const double* Qc, double dt, double t
   return GPMP2MI_OK;
 }
 
+int gpmp2mi_interpolate_traj_dev(int D, int lie, double dt, int inter, int B, int N, int start, int end,
+                                 const double* traj, double* out, void* stream) {
+  G2_CHECK(traj && out && B >= 0 && D > 0 && inter >= 0 && dt > 0, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_CHECK(start >= 0 && start < end && end <= N, GPMP2MI_ERR_INVALID, "need 0 <= start_index < end_index <= total_step");
+  if (B == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  const long long Mo = (long long)(end - start) * (inter + 1) + 1;
+  G2_CHECK(Mo * B < (1ll << 31), GPMP2MI_ERR_INVALID, "too many output states for one launch");
+  return launch_interpolate_traj(D, lie != 0, dt, inter, B, N, start, (int)Mo, traj, out, (hipStream_t)stream);
+}
+
+int gpmp2mi_interpolate_traj(int D, int lie, const double* Qc, double dt, int inter, int B, int N, int start,
+                             int end, const double* traj, double* out) {
+  (void)Qc;
+  G2_CHECK(traj && out && B >= 0 && D > 0 && inter >= 0, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_CHECK(start >= 0 && start < end && end <= N, GPMP2MI_ERR_INVALID, "need 0 <= start_index < end_index <= total_step");
+  if (B == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  const size_t Mo = (size_t)(end - start) * (inter + 1) + 1;
+  DevBuf<double> a, o;
+  G2_TRY(a.upload(traj, (size_t)B * (N + 1) * 2 * D));
+  G2_TRY(o.alloc((size_t)B * Mo * 2 * D));
+  G2_TRY(gpmp2mi_interpolate_traj_dev(D, lie, dt, inter, B, N, start, end, a.p, o.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(o.download(out));
+  return GPMP2MI_OK;
+}
+
 int gpmp2mi_joint_limit_factor(int D, const double* down, const double* up, const double* th, int M,
                                const double* x, double* err, double* Hd) {
   G2_CHECK(down && up && th && x && err && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");

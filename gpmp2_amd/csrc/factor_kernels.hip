@@ -398,6 +398,66 @@ __global__ void k_gp_interp_lie(GpCoef gc, int M, const double* __restrict__ c1,
   }
 }
 
+// Lambda / Psi scalars of one sub-step (gpmp2/gp/GPutils.h:44-59 with Qc factored out); device twin of
+// the host gp_coef in api.hip so that a densify launch needs no coefficient upload
+__device__ __forceinline__ GpCoef gp_coef_dev(double dt, double tau) {
+  const double a0 = tau * tau * tau / 3.0, a1 = 0.5 * tau * tau, r = dt - tau;
+  const double w0 = 12.0 / (dt * dt * dt), w1 = -6.0 / (dt * dt), w3 = 4.0 / dt;
+  // T = A(tau) Phi(dt - tau)^T ;  Psi = T Q^-1(dt)
+  const double t0 = a0 + a1 * r, t1 = a1, t2 = a1 + tau * r, t3 = tau;
+  GpCoef c;
+  c.p11 = t0 * w0 + t1 * w1;
+  c.p12 = t0 * w1 + t1 * w3;
+  c.p21 = t2 * w0 + t3 * w1;
+  c.p22 = t2 * w1 + t3 * w3;
+  c.l11 = 1.0 - c.p11;
+  c.l12 = tau - (c.p11 * dt + c.p12);
+  c.l21 = -c.p21;
+  c.l22 = 1.0 - (c.p21 * dt + c.p22);
+  return c;
+}
+
+// interpolateArmTraj / interpolatePose2MobileArmTraj  gpmp2/planner/TrajUtils.cpp:162-236
+// one thread per output state: support state i copies, the inter_step states after it interpolate
+// between i and i + 1 at tau = j * delta_t / (inter_step + 1).  traj [B][N+1][2D] -> out [B][Mo][2D]
+template <int D, bool LIE>
+__global__ void k_interpolate_traj(double dt, int inter, int B, int N, int start, int Mo,
+                                   const double* __restrict__ traj, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * Mo) return;
+  const int b = t / Mo, m = t % Mo;
+  const int seg = m / (inter + 1), j = m % (inter + 1);
+  const double* s0 = traj + ((size_t)b * (N + 1) + start + seg) * 2 * D;
+  double* o = out + (size_t)t * 2 * D;
+  if (j == 0) {
+#pragma unroll
+    for (int k = 0; k < 2 * D; k++) o[k] = s0[k];
+    return;
+  }
+  const double* s1 = s0 + 2 * D;
+  const GpCoef gc = gp_coef_dev(dt, (double)j * (dt / (double)(inter + 1)));
+  double x0[D], w0[D], x1[D], w1[D];
+#pragma unroll
+  for (int k = 0; k < D; k++) { x0[k] = s0[k]; w0[k] = s0[D + k]; x1[k] = s1[k]; w1[k] = s1[D + k]; }
+  if constexpr (LIE) {
+    double q[D], lg[3];
+    lie_interpolate<D>(gc, x0, w0, x1, w1, q, nullptr);
+    pose2_logmap(pose2_between(P2{x0[0], x0[1], x0[2]}, P2{x1[0], x1[1], x1[2]}), lg);
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const double r = (k < 3) ? lg[k] : (x1[k] - x0[k]);
+      o[k] = q[k];
+      o[D + k] = gc.l22 * w0[k] + gc.p21 * r + gc.p22 * w1[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      o[k] = gc.l11 * x0[k] + gc.l12 * w0[k] + gc.p11 * x1[k] + gc.p12 * w1[k];
+      o[D + k] = gc.l21 * x0[k] + gc.l22 * w0[k] + gc.p21 * x1[k] + gc.p22 * w1[k];
+    }
+  }
+}
+
 // JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
 __global__ void k_joint_limit(int D, const double* __restrict__ down, const double* __restrict__ up,
                               const double* __restrict__ th, int M, const double* __restrict__ x,
@@ -462,6 +522,23 @@ int launch_gp_prior_linear(int D, double dt, int M, const double* c1, const doub
 int launch_gp_interp_linear(int D, const GpCoef& gc, int M, const double* c1, const double* v1,
                             const double* c2, const double* v2, double* conf, double* vel, hipStream_t st) {
   k_gp_interp_linear<<<G2_GRID(M)>>>(D, gc, M, c1, v1, c2, v2, conf, vel);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N, int start, int Mo,
+                            const double* traj, double* out, hipStream_t st) {
+  const int M = B * Mo;
+  if (lie && D < 3) { set_error("Pose2Vector dof must be 3..10"); return GPMP2MI_ERR_UNSUPPORTED; }
+  switch (D) {
+#define G2_IT(DD) case DD: \
+    if (lie) { if constexpr (DD >= 3) k_interpolate_traj<DD, true><<<G2_GRID(M)>>>(dt, inter, B, N, start, Mo, traj, out); } \
+    else k_interpolate_traj<DD, false><<<G2_GRID(M)>>>(dt, inter, B, N, start, Mo, traj, out); \
+    break;
+    G2_IT(1) G2_IT(2) G2_IT(3) G2_IT(4) G2_IT(5) G2_IT(6) G2_IT(7) G2_IT(8) G2_IT(9) G2_IT(10)
+#undef G2_IT
+    default: set_error("dof must be 1..10"); return GPMP2MI_ERR_UNSUPPORTED;
+  }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

@@ -25,6 +25,8 @@ int launch_gp_interp_linear(int D, const GpCoef& gc, int M, const double* c1, co
 int launch_gp_prior_lie(int D, double dt, int M, const double* c1, const double* v1, const double* c2,
                         const double* v2, double* err, double* H1, double* H2, double* H3, double* H4,
                         hipStream_t st);
+int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N, int start, int Mo,
+                            const double* traj, double* out, hipStream_t st);
 int launch_gp_interp_lie(int D, const GpCoef& gc, int M, const double* c1, const double* v1, const double* c2,
                          const double* v2, double* conf, double* vel, hipStream_t st);
 int launch_joint_limit(int D, const double* down, const double* up, const double* th, int M,

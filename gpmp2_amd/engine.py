@@ -17,6 +17,10 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libgpmp2mi.so")
 ERR_NAMES = {1: "invalid argument", 2: "no usable GPU", 3: "HIP error", 4: "unsupported", 5: "allocation failed"}
 
 
+# per-trajectory status (include/gpmp2mi.h:51-59)
+TRAJ_CONVERGED, TRAJ_MAX_ITER, TRAJ_ROLLED_BACK, TRAJ_NOT_SPD, TRAJ_ALREADY_OPTIMAL = range(5)
+
+
 class Gpmp2miError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"gpmp2mi error {code} ({ERR_NAMES.get(code, '?')}): {msg}")
@@ -149,6 +153,18 @@ class Engine:
         self._ck(self.lib.gpmp2mi_gp_interpolate(dof, int(lie), dptr(Q), C.c_double(delta_t), C.c_double(tau),
                                                  M, dptr(c1), dptr(v1), dptr(c2), dptr(v2), dptr(conf), dptr(vel)))
         return conf, vel
+
+    def interpolate_traj(self, dof, lie, Qc, delta_t, inter_step, traj, start_index=0, end_index=None):
+        """traj [B][N+1][2D] -> [B][(end-start)*(inter_step+1)+1][2D]  (planner/TrajUtils.cpp:96-236)"""
+        t = f64(traj)
+        t = t.reshape(-1, t.shape[-2], 2 * dof)
+        B, N = t.shape[0], t.shape[1] - 1
+        end_index = N if end_index is None else int(end_index)
+        Q = None if Qc is None else f64(Qc)
+        out = np.zeros((B, max(end_index - start_index, 0) * (inter_step + 1) + 1, 2 * dof))
+        self._ck(self.lib.gpmp2mi_interpolate_traj(dof, int(lie), dptr(Q), C.c_double(delta_t), int(inter_step), B, N,
+                                               int(start_index), end_index, dptr(t), dptr(out)))
+        return out
 
     def joint_limit_factor(self, down, up, thresh, x):
         down, up, thresh = f64(down).reshape(-1), f64(up).reshape(-1), f64(thresh).reshape(-1)

@@ -296,6 +296,20 @@ int gpmp2mi_gp_interpolate(int dof, int lie, const double* Qc, double delta_t, d
                            const double* conf1, const double* vel1, const double* conf2,
                            const double* vel2, double* conf, double* vel);
 
+/* gpmp2::interpolateArmTraj (both overloads) / interpolatePose2MobileArmTraj
+ * planner/TrajUtils.cpp:96-236: up-sample B trajectories with inter_step GP-interpolated states
+ * inside every interval of [start_index, end_index] (0 <= start_index < end_index <= total_step;
+ * the no-range overload of the reference is start_index = 0, end_index = total_step).
+ * traj [B][total_step+1][2D] -> out [B][(end_index - start_index)*(inter_step+1) + 1][2D].
+ * Qc is accepted for interface parity; Lambda and Psi do not depend on it (gp/GPutils.h:44-59). */
+int gpmp2mi_interpolate_traj(int dof, int lie, const double* Qc, double delta_t, int inter_step,
+                             int B, int total_step, int start_index, int end_index,
+                             const double* traj, double* out);
+/* same on device pointers, enqueued on `stream` (e.g. traj = gpmp2mi_plan_traj_dev(plan)) */
+int gpmp2mi_interpolate_traj_dev(int dof, int lie, double delta_t, int inter_step, int B,
+                                 int total_step, int start_index, int end_index,
+                                 const double* traj, double* out, void* stream);
+
 /* JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
  * kinematics/JointLimitFactorVector.h:62-79, kinematics/VelocityLimitFactorVector.h:62-79.
  * x [M][D] -> err [M][D], Hdiag [M][D] (the diagonal of the Jacobian). */

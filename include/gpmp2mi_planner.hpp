@@ -6,6 +6,7 @@
 //   gpmp2::TrajOptimizerSetting                         gpmp2/planner/TrajOptimizerSetting.h:17-100
 //   gpmp2::BatchTrajOptimize3DArm / 2DArm               gpmp2/planner/BatchTrajOptimizer.h:43-56
 //   gpmp2::CollisionCost3DArm / 2DArm                   gpmp2/planner/BatchTrajOptimizer.h:135-147
+//   gpmp2::ISAM2TrajOptimizer2DArm / 3DArm              gpmp2/planner/ISAM2TrajOptimizer.h:143-156
 //   gpmp2::initArmTrajStraightLine                      gpmp2/planner/TrajUtils.cpp:25-50
 //
 // The reference passes gtsam::Values / gtsam::Vector / gtsam::Pose3.  GTSAM, Boost and Eigen are not part of
@@ -344,6 +345,98 @@ inline double CollisionCost2DArm(const ArmModel& arm, const PlanarSDF& sdf, cons
         "gpmp2mi_collision_cost");
   return c;
 }
+
+namespace internal {
+/// gpmp2::internal::ISAM2TrajOptimizer  gpmp2/planner/ISAM2TrajOptimizer.h:58-137
+/// Same call sequence as the reference (initFactorGraph, initValues, update, then the replanning
+/// interface and update again); each update() is one full relinearise + solve of the resident plan
+/// (gpmp2mi_plan_update), not an iSAM2 partial update -- see include/gpmp2mi.h.
+template <class ROBOT, class SDF>
+class ISAM2TrajOptimizer {
+ public:
+  ISAM2TrajOptimizer(const ROBOT& arm, const SDF& sdf, const TrajOptimizerSetting& setting)
+      : dof_(arm.dof()), setting_(setting) {
+    const gpmp2mi_settings s = setting_.c_struct();
+    check(gpmp2mi_plan_create(arm.handle(), sdf.handle(), &s, nullptr, 1, &plan_), "gpmp2mi_plan_create");
+  }
+  ~ISAM2TrajOptimizer() {
+    if (plan_) gpmp2mi_plan_destroy(plan_);
+  }
+  ISAM2TrajOptimizer(const ISAM2TrajOptimizer&) = delete;
+  ISAM2TrajOptimizer& operator=(const ISAM2TrajOptimizer&) = delete;
+
+  /// ISAM2TrajOptimizer-inl.h:28-84
+  void initFactorGraph(const Vector& start_conf, const Vector& start_vel, const Vector& goal_conf, const Vector& goal_vel) {
+    start_conf_ = start_conf, start_vel_ = start_vel, goal_conf_ = goal_conf, goal_vel_ = goal_vel;
+    fits(start_conf), fits(start_vel), fits(goal_conf), fits(goal_vel);
+    have_graph_ = true;
+  }
+  /// ISAM2TrajOptimizer-inl.h:90-96
+  void initValues(const Trajectory& init_values) {
+    if (!have_graph_) throw std::runtime_error("[ISAM2TrajOptimizer] initFactorGraph must come first");
+    if (init_values.dof != dof_ || init_values.total_step != setting_.total_step)
+      throw std::runtime_error("[ISAM2TrajOptimizer] init_values do not match dof / total_step");
+    check(gpmp2mi_plan_set_problem(plan_, start_conf_.data(), start_vel_.data(), goal_conf_.data(), goal_vel_.data(),
+                                   init_values.data.data()),
+          "gpmp2mi_plan_set_problem");
+    opt_values_ = init_values;
+  }
+  /// ISAM2TrajOptimizer-inl.h:102-114
+  void update() {
+    check(gpmp2mi_plan_update(plan_, 1, nullptr), "gpmp2mi_plan_update");
+    int status = 0;
+    check(gpmp2mi_plan_get_result(plan_, opt_values_.data.data(), nullptr, nullptr, &status, nullptr),
+          "gpmp2mi_plan_get_result");
+    if (status == GPMP2MI_TRAJ_NOT_SPD) throw std::runtime_error("[gpmp2mi] IndeterminantLinearSystemException");
+  }
+  /// ISAM2TrajOptimizer-inl.h:120-141
+  void changeGoalConfigAndVel(const Vector& goal_conf, const Vector& goal_vel) {
+    fits(goal_conf), fits(goal_vel);
+    check(gpmp2mi_plan_change_goal(plan_, 0, goal_conf.data(), goal_vel.data()), "gpmp2mi_plan_change_goal");
+  }
+  /// ISAM2TrajOptimizer-inl.h:147-153
+  void removeGoalConfigAndVel() { check(gpmp2mi_plan_remove_goal(plan_, 0), "gpmp2mi_plan_remove_goal"); }
+  /// ISAM2TrajOptimizer-inl.h:159-168
+  void fixConfigAndVel(std::size_t state_idx, const Vector& conf_fix, const Vector& vel_fix) {
+    fits(conf_fix), fits(vel_fix);
+    check(gpmp2mi_plan_fix_state(plan_, 0, static_cast<int>(state_idx), conf_fix.data(), vel_fix.data()),
+          "gpmp2mi_plan_fix_state");
+  }
+  /// ISAM2TrajOptimizer-inl.h:174-180; pose_cov row-major [dof][dof]
+  void addPoseEstimate(std::size_t state_idx, const Vector& pose, const Vector& pose_cov) {
+    fits(pose);
+    if (pose_cov.size() != dof_ * dof_) throw std::runtime_error("[ISAM2TrajOptimizer] covariance dim does not fit dof");
+    check(gpmp2mi_plan_add_state_estimate(plan_, 0, static_cast<int>(state_idx), pose.data(), pose_cov.data(), nullptr,
+                                          nullptr),
+          "gpmp2mi_plan_add_state_estimate");
+  }
+  /// ISAM2TrajOptimizer-inl.h:186-195
+  void addStateEstimate(std::size_t state_idx, const Vector& pose, const Vector& pose_cov, const Vector& vel,
+                        const Vector& vel_cov) {
+    fits(pose), fits(vel);
+    if (pose_cov.size() != dof_ * dof_ || vel_cov.size() != dof_ * dof_)
+      throw std::runtime_error("[ISAM2TrajOptimizer] covariance dim does not fit dof");
+    check(gpmp2mi_plan_add_state_estimate(plan_, 0, static_cast<int>(state_idx), pose.data(), pose_cov.data(),
+                                          vel.data(), vel_cov.data()),
+          "gpmp2mi_plan_add_state_estimate");
+  }
+  const Trajectory& values() const { return opt_values_; }
+
+ private:
+  void fits(const Vector& v) const {
+    if (v.size() != dof_) throw std::runtime_error("[ISAM2TrajOptimizer] vector dim does not fit dof");
+  }
+  std::size_t dof_;
+  TrajOptimizerSetting setting_;
+  gpmp2mi_plan* plan_ = nullptr;
+  Vector start_conf_, start_vel_, goal_conf_, goal_vel_;
+  Trajectory opt_values_;
+  bool have_graph_ = false;
+};
+}  // namespace internal
+/// gpmp2/planner/ISAM2TrajOptimizer.h:143-156
+typedef internal::ISAM2TrajOptimizer<ArmModel, PlanarSDF> ISAM2TrajOptimizer2DArm;
+typedef internal::ISAM2TrajOptimizer<ArmModel, SignedDistanceField> ISAM2TrajOptimizer3DArm;
 
 #ifdef GPMP2MI_HAVE_GTSAM
 /// gtsam::Values (keys Symbol('x', i) / Symbol('v', i), gpmp2/planner/BatchTrajOptimizer.h:39-41) <-> Trajectory

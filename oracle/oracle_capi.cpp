@@ -212,6 +212,36 @@ int orc_gp_interpolate(int D, int lie, const double* Qc, double dt, double tau, 
   return 0;
 }
 
+// interpolateArmTraj / interpolatePose2MobileArmTraj  gpmp2/planner/TrajUtils.cpp:162-236
+// traj [B][N+1][2D] -> out [B][(end-start)*(inter+1)+1][2D]
+int orc_interpolate_traj(int D, int lie, const double* Qc, double dt, int inter, int B, int N, int start,
+                         int end, const double* traj, double* out) {
+  Mat Q = Mat::identity(D);
+  if (Qc)
+    for (int i = 0; i < D * D; i++) Q.a[i] = Qc[i];
+  const double inter_dt = dt / static_cast<double>(inter + 1);
+  std::vector<GPInterp> gp;
+  for (int j = 1; j <= inter; j++) gp.emplace_back(D, lie != 0, Q, dt, static_cast<double>(j) * inter_dt);
+  const size_t Mo = (size_t)(end - start) * (inter + 1) + 1;
+  for (int b = 0; b < B; b++) {
+    const double* t = traj + (size_t)b * (N + 1) * 2 * D;
+    double* o = out + (size_t)b * Mo * 2 * D;
+    size_t ri = 0;
+    for (int i = start; i < end; i++) {
+      std::memcpy(o + ri * 2 * D, t + (size_t)i * 2 * D, sizeof(double) * 2 * D);
+      const double *c1 = t + (size_t)i * 2 * D, *v1 = c1 + D, *c2 = c1 + 2 * D, *v2 = c2 + D;
+      for (int j = 1; j <= inter; j++) {
+        ri++;
+        gp[j - 1].interpolate_pose(c1, v1, c2, v2, o + ri * 2 * D, nullptr, nullptr, nullptr, nullptr);
+        gp[j - 1].interpolate_velocity(c1, v1, c2, v2, o + ri * 2 * D + D);
+      }
+      ri++;
+    }
+    std::memcpy(o + ri * 2 * D, t + (size_t)end * 2 * D, sizeof(double) * 2 * D);
+  }
+  return 0;
+}
+
 // Jacobians of interpolatePose (H1..H4 [M][D][D]) -- used to pin the Lie interpolator
 int orc_gp_interpolate_jac(int D, int lie, const double* Qc, double dt, double tau, int M,
                            const double* c1, const double* v1, const double* c2,

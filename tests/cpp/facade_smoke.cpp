@@ -35,6 +35,22 @@ int main() {
     const Trajectory out = BatchTrajOptimize2DArm(model, sdf, start, zero, end, zero, init, setting, &iters, &err);
     std::printf("OK iterations=%d final_error=%.6f x_5=(%.4f, %.4f) collision=%.4f\n", iters, err, out.x(5)[0],
                 out.x(5)[1], CollisionCost2DArm(model, sdf, out, setting));
+    // replanner: batch answer as initial values, fix state 3 where it is, move the goal, two updates
+    ISAM2TrajOptimizer2DArm isam(model, sdf, setting);
+    isam.initFactorGraph(start, zero, end, zero);
+    isam.initValues(out);
+    isam.update();
+    const Vector fix_c{isam.values().x(3)[0], isam.values().x(3)[1]}, fix_v{isam.values().v(3)[0], isam.values().v(3)[1]};
+    const Vector goal2{1.2, 0.9};
+    isam.fixConfigAndVel(3, fix_c, fix_v);
+    isam.changeGoalConfigAndVel(goal2, zero);
+    isam.update();
+    isam.update();
+    const Trajectory& re = isam.values();
+    const double dfix = std::hypot(re.x(3)[0] - fix_c[0], re.x(3)[1] - fix_c[1]);
+    const double dgoal = std::hypot(re.x(10)[0] - goal2[0], re.x(10)[1] - goal2[1]);
+    std::printf("REPLAN fixed_state_drift=%.2e goal_miss=%.2e\n", dfix, dgoal);
+    if (dfix > 1e-3 || dgoal > 1e-3) return 4;
     return 0;
   } catch (const std::exception& e) {
     std::printf("EXCEPTION %s\n", e.what());

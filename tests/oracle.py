@@ -143,6 +143,18 @@ class Oracle:
         self.lib.orc_gp_matrices(dof, dptr(Q), C.c_double(delta_t), C.c_double(tau), dptr(L), dptr(P))
         return L, P
 
+    def interpolate_traj(self, dof, lie, Qc, delta_t, inter_step, traj, start_index=0, end_index=None):
+        """traj [B][N+1][2D] -> [B][(end-start)*(inter_step+1)+1][2D]  (planner/TrajUtils.cpp:96-236)"""
+        t = f64(traj)
+        t = t.reshape(-1, t.shape[-2], 2 * dof)
+        B, N = t.shape[0], t.shape[1] - 1
+        end_index = N if end_index is None else int(end_index)
+        Q = None if Qc is None else f64(Qc)
+        out = np.zeros((B, max(end_index - start_index, 0) * (inter_step + 1) + 1, 2 * dof))
+        self.lib.orc_interpolate_traj(dof, int(lie), dptr(Q), C.c_double(delta_t), int(inter_step), B, N,
+                                      int(start_index), end_index, dptr(t), dptr(out))
+        return out
+
     def joint_limit_factor(self, down, up, thresh, x):
         down, up, thresh = f64(down).reshape(-1), f64(up).reshape(-1), f64(thresh).reshape(-1)
         D = down.size

@@ -388,3 +388,54 @@ def test_vehicle_dynamics_and_pose2_prior_in_graph(oracle):
     f0 = oracle.graph_error(r, s, p.setting, p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
     f1 = oracle.graph_error(r, s, p.setting, p.start_conf, p.start_vel, p.end_conf, p.end_vel, traj)
     np.testing.assert_allclose((e1 - e0) - (f1 - f0), expected, rtol=1e-9)
+
+
+# ------------------------------------------------------------------ TrajUtils (testTrajUtils.cpp)
+def test_interpolate_arm_traj_known_answer(oracle, golden):
+    d = golden["traj_utils"]
+    traj = np.concatenate([np.array(d["x"], dtype=float), np.array(d["v"], dtype=float)], axis=1)  # [2][2D]
+    out = oracle.interpolate_traj(2, False, np.array(d["Qc"]), d["delta_t"], d["inter_step"], traj[None])[0]
+    np.testing.assert_allclose(out[:, :2], d["expected_x"], atol=d["tol"])
+    np.testing.assert_allclose(out[:, 2:], d["expected_v"], atol=d["tol"])
+
+
+def test_interpolate_traj_ranges_and_support_states(oracle):
+    """both reference overloads agree on the full range; support states are copied verbatim and a
+    sub-range is the matching slice (TrajUtils.cpp:96-197)"""
+    rng = np.random.default_rng(5)
+    D, N, I = 3, 6, 3
+    traj = rng.normal(size=(2, N + 1, 2 * D))
+    full = oracle.interpolate_traj(D, False, None, 0.25, I, traj)
+    assert full.shape == (2, N * (I + 1) + 1, 2 * D)
+    np.testing.assert_array_equal(full[:, ::I + 1], traj)
+    part = oracle.interpolate_traj(D, False, None, 0.25, I, traj, 2, 5)
+    np.testing.assert_array_equal(part, full[:, 2 * (I + 1):5 * (I + 1) + 1])
+    conf, vel = oracle.gp_interpolate(D, False, None, 0.25, 2 * 0.25 / (I + 1), traj[:, 1, :D], traj[:, 1, D:],
+                                      traj[:, 2, :D], traj[:, 2, D:])
+    np.testing.assert_allclose(full[:, (I + 1) + 2, :D], conf, atol=1e-14)
+    np.testing.assert_allclose(full[:, (I + 1) + 2, D:], vel, atol=1e-14)
+
+
+def test_init_pose2vector_traj_straight_line(oracle, golden):
+    d = golden["traj_utils"]["init_pose2vector"]
+    t = g.initPose2VectorTrajStraightLine(vec(d["init_pose"]), d["init_conf"], vec(d["end_pose"]), d["end_conf"],
+                                          d["total_step"])
+    np.testing.assert_allclose(t[0, :5], vec(d["expected_x0"]), atol=d["tol"])
+    # end state and average velocity (TrajUtils.cpp:58-60: plain coordinate difference, no angle wrap)
+    end = np.concatenate([vec(d["end_pose"]), d["end_conf"]])
+    np.testing.assert_allclose(t[-1, :5], end, atol=1e-12)
+    np.testing.assert_allclose(t[2, 5:], (end - vec(d["expected_x0"])) / d["total_step"], atol=1e-15)
+    # the pose part follows the geodesic through the +-pi cut: theta goes pi-0.5 -> pi -> -pi+0.5
+    th = np.unwrap(t[:, 2])
+    np.testing.assert_allclose(np.diff(th), 0.2, atol=1e-12)
+
+
+def test_host_pose2_helpers_match_oracle(oracle):
+    from gpmp2_amd import trajutils as tu
+    rng = np.random.default_rng(9)
+    for _ in range(20):
+        v = rng.normal(size=3) * np.array([2.0, 2.0, 1.5])
+        p = oracle.pose2_expmap(v)
+        np.testing.assert_allclose(tu.pose2_expmap(v), p, atol=1e-14)
+        np.testing.assert_allclose(tu.pose2_logmap(p), oracle.pose2_logmap(p), atol=1e-13)
+    np.testing.assert_allclose(tu.pose2_expmap(np.array([0.3, -0.2, 0.0])), [0.3, -0.2, 0.0])
