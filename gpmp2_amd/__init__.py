@@ -4,8 +4,7 @@ The compute path is the HIP library gpmp2_amd/csrc/libgpmp2mi.so behind the C AB
 include/gpmp2mi.h; this package is the reference-shaped façade over it (robots, SDFs, settings,
 BatchTrajOptimize*, factor evaluateError) used by tests and bench.py.
 """
-from .datasets import (generate2Ddataset, generate3Ddataset, sdf3_zyx, signedDistanceField2D,  # noqa: F401
-                       signedDistanceField3D)
+from .datasets import generate2Ddataset, generate3Ddataset, sdf3_zyx  # noqa: F401
 from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pose2MobileArm,  # noqa: F401
                      Pose2MobileArmModel, Pose2MobileBase, Pose2MobileBaseModel, generateArm,
                      generateMobileArm, generatePointRobot, pose3, rot_yaw)
@@ -13,7 +12,8 @@ from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajO
                       BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,
                       ISAM2TrajOptimizer3DArm, ISAM2TrajOptimizerPose2MobileArm, ISAM2TrajOptimizerPose2MobileArm2D,
-                      PlanarSDF, SDFQueryOutOfRange, SignedDistanceField)
+                      PlanarSDF, SDFQueryOutOfRange, SignedDistanceField, readSDFvolfile, signedDistanceField2D,
+                      signedDistanceField3D)
 from .settings import TrajOptimizerSetting  # noqa: F401
 from .trajutils import (initArmTrajStraightLine, initPose2TrajStraightLine, initPose2VectorTrajStraightLine,  # noqa: F401
                         interpolateArmTraj, interpolatePose2MobileArmTraj, interpolatePose2Traj, traj_from_values,

@@ -8,6 +8,7 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <fstream>
 #include <vector>
 
 #include "common.h"
@@ -48,12 +49,6 @@ struct DevBuf {
     if (p) (void)hipFree(p);
   }
 };
-#define G2_TRY(expr)             \
-  do {                           \
-    int rc_ = (expr);            \
-    if (rc_ != GPMP2MI_OK) return rc_; \
-  } while (0)
-
 static int ensure_device() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -320,27 +315,14 @@ int gpmp2mi_robot_nr_links(const gpmp2mi_robot* r) { return r ? r->h.nr_links : 
 int gpmp2mi_robot_nr_spheres(const gpmp2mi_robot* r) { return r ? r->h.nr_spheres : -1; }
 
 // -------------------------------------------------------------------------------------------- sdf
-int gpmp2mi_sdf_create(int dim, const double origin[3], double cell, int nx, int ny, int nz,
-                       const double* vox, int layout, gpmp2mi_sdf** out) {
-  G2_CHECK(out && origin && vox, GPMP2MI_ERR_INVALID, "null argument");
-  *out = nullptr;
+// geometry + device storage of a field handle; the caller fills s->plain ([nz][ny][nx]) and packs
+static int sdf_alloc(int dim, const double origin[3], double cell, int nx, int ny, int nz,
+                     std::unique_ptr<gpmp2mi_sdf>& s) {
   G2_CHECK(dim == 2 || dim == 3, GPMP2MI_ERR_INVALID, "dim must be 2 or 3");
-  if (dim == 2) nz = 1;
   G2_CHECK(nx > 0 && ny > 0 && nz > 0 && cell > 0, GPMP2MI_ERR_INVALID, "bad field size");
   G2_TRY(ensure_device());
-  auto s = std::make_unique<gpmp2mi_sdf>();
+  s = std::make_unique<gpmp2mi_sdf>();
   const size_t n = (size_t)nx * ny * nz;
-  std::vector<double> zyx;
-  const double* src = vox;
-  if (layout == GPMP2MI_SDF_LAYOUT_GTSAM) {
-    zyx.resize(n);
-    for (int z = 0; z < nz; z++)
-      for (int y = 0; y < ny; y++)
-        for (int x = 0; x < nx; x++) zyx[((size_t)z * ny + y) * nx + x] = vox[((size_t)z * nx + x) * ny + y];
-    src = zyx.data();
-  } else {
-    G2_CHECK(layout == GPMP2MI_SDF_LAYOUT_ZYX, GPMP2MI_ERR_INVALID, "unknown voxel layout");
-  }
   SdfDev& h = s->h;
   h.dim = dim;
   h.nx = nx;
@@ -356,15 +338,120 @@ int gpmp2mi_sdf_create(int dim, const double origin[3], double cell, int nx, int
   h.hiy = h.oy + (ny - 1.0) * cell;
   h.hiz = h.oz + (nz - 1.0) * cell;
   G2_HIP(hipMalloc((void**)&s->plain, n * sizeof(double)));
-  G2_HIP(hipMemcpy(s->plain, src, n * sizeof(double), hipMemcpyHostToDevice));
   const int nc = dim == 3 ? 8 : 4;
   G2_HIP(hipMalloc((void**)&s->cells, n * nc * sizeof(double)));
   h.plain = s->plain;
   h.cells = s->cells;
-  G2_TRY(launch_sdf_pack(h, s->cells, nullptr));
+  return GPMP2MI_OK;
+}
+
+// caller layout -> [nz][ny][nx]
+static const double* to_zyx(const double* vox, int layout, int nx, int ny, int nz, std::vector<double>& tmp) {
+  if (layout != GPMP2MI_SDF_LAYOUT_GTSAM) return vox;
+  tmp.resize((size_t)nx * ny * nz);
+  for (int z = 0; z < nz; z++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++) tmp[((size_t)z * ny + y) * nx + x] = vox[((size_t)z * nx + x) * ny + y];
+  return tmp.data();
+}
+
+int gpmp2mi_sdf_create(int dim, const double origin[3], double cell, int nx, int ny, int nz,
+                       const double* vox, int layout, gpmp2mi_sdf** out) {
+  G2_CHECK(out && origin && vox, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (dim == 2) nz = 1;
+  G2_CHECK(layout == GPMP2MI_SDF_LAYOUT_ZYX || layout == GPMP2MI_SDF_LAYOUT_GTSAM, GPMP2MI_ERR_INVALID,
+           "unknown voxel layout");
+  std::unique_ptr<gpmp2mi_sdf> s;
+  G2_TRY(sdf_alloc(dim, origin, cell, nx, ny, nz, s));
+  std::vector<double> tmp;
+  const double* src = to_zyx(vox, layout, nx, ny, nz, tmp);
+  G2_HIP(hipMemcpy(s->plain, src, (size_t)nx * ny * nz * sizeof(double), hipMemcpyHostToDevice));
+  G2_TRY(launch_sdf_pack(s->h, s->cells, nullptr));
   G2_HIP(hipDeviceSynchronize());
   *out = s.release();
   return GPMP2MI_OK;
+}
+
+int gpmp2mi_sdf_field_from_occupancy(int dim, int nx, int ny, int nz, const double* occ, double cell,
+                                     double* field) {
+  G2_CHECK(occ && field, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(dim == 2 || dim == 3, GPMP2MI_ERR_INVALID, "dim must be 2 or 3");
+  if (dim == 2) nz = 1;
+  G2_CHECK(nx > 0 && ny > 0 && nz > 0 && cell > 0, GPMP2MI_ERR_INVALID, "bad grid size");
+  G2_TRY(ensure_device());
+  const size_t n = (size_t)nx * ny * nz;
+  DevBuf<double> d_occ, d_field;
+  DevBuf<int> wa, wb;
+  G2_TRY(d_occ.upload(occ, n));
+  G2_TRY(d_field.alloc(n));
+  G2_TRY(wa.alloc(n));
+  G2_TRY(wb.alloc(n));
+  G2_TRY(launch_sdf_from_occupancy(nx, ny, nz, d_occ.p, cell, wa.p, wb.p, d_field.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  return d_field.download(field);
+}
+
+int gpmp2mi_sdf_create_from_occupancy(int dim, const double origin[3], double cell, int nx, int ny, int nz,
+                                      const double* occ, int layout, gpmp2mi_sdf** out) {
+  G2_CHECK(out && origin && occ, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (dim == 2) nz = 1;
+  G2_CHECK(layout == GPMP2MI_SDF_LAYOUT_ZYX || layout == GPMP2MI_SDF_LAYOUT_GTSAM, GPMP2MI_ERR_INVALID,
+           "unknown voxel layout");
+  std::unique_ptr<gpmp2mi_sdf> s;
+  G2_TRY(sdf_alloc(dim, origin, cell, nx, ny, nz, s));
+  const size_t n = (size_t)nx * ny * nz;
+  std::vector<double> tmp;
+  DevBuf<double> d_occ;
+  DevBuf<int> wa, wb;
+  G2_TRY(d_occ.upload(to_zyx(occ, layout, nx, ny, nz, tmp), n));
+  G2_TRY(wa.alloc(n));
+  G2_TRY(wb.alloc(n));
+  G2_TRY(launch_sdf_from_occupancy(nx, ny, nz, d_occ.p, cell, wa.p, wb.p, s->plain, nullptr));
+  G2_TRY(launch_sdf_pack(s->h, s->cells, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  *out = s.release();
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_sdf_get_field(const gpmp2mi_sdf* s, int* dim, int* nx, int* ny, int* nz, double origin[3],
+                          double* cell, double* field) {
+  G2_CHECK(s, GPMP2MI_ERR_INVALID, "null argument");
+  if (dim) *dim = s->h.dim;
+  if (nx) *nx = s->h.nx;
+  if (ny) *ny = s->h.ny;
+  if (nz) *nz = s->h.nz;
+  if (origin) origin[0] = s->h.ox, origin[1] = s->h.oy, origin[2] = s->h.oz;
+  if (cell) *cell = s->h.cell;
+  if (field)
+    G2_HIP(hipMemcpy(field, s->plain, (size_t)s->h.nx * s->h.ny * s->h.nz * sizeof(double), hipMemcpyDeviceToHost));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_sdf_read_vol(const char* filename_pre, gpmp2mi_sdf** out) {
+  G2_CHECK(filename_pre && out, GPMP2MI_ERR_INVALID, "null argument");
+  *out = nullptr;
+  const std::string pre(filename_pre);
+  std::ifstream head(pre + ".vol.head");
+  G2_CHECK(head.is_open(), GPMP2MI_ERR_INVALID, "cannot open " + pre + ".vol.head");
+  long long cols = 0, rows = 0, nz = 0;
+  double origin[3] = {0, 0, 0}, res = 0;
+  head >> cols >> rows >> nz >> origin[0] >> origin[1] >> origin[2] >> res;
+  G2_CHECK(!head.fail() && cols > 0 && rows > 0 && nz > 0 && res > 0, GPMP2MI_ERR_INVALID, "malformed " + pre + ".vol.head");
+  std::ifstream data(pre + ".vol.data");
+  G2_CHECK(data.is_open(), GPMP2MI_ERR_INVALID, "cannot open " + pre + ".vol.data");
+  // x outermost, then y, then z (fileUtils.cpp:48-55)
+  std::vector<double> zyx((size_t)cols * rows * nz);
+  for (long long x = 0; x < cols; x++)
+    for (long long y = 0; y < rows; y++)
+      for (long long z = 0; z < nz; z++) {
+        double v;
+        data >> v;
+        G2_CHECK(!data.fail(), GPMP2MI_ERR_INVALID, "short or malformed " + pre + ".vol.data");
+        zyx[((size_t)z * rows + y) * cols + x] = v;
+      }
+  return gpmp2mi_sdf_create(3, origin, res, (int)cols, (int)rows, (int)nz, zyx.data(), GPMP2MI_SDF_LAYOUT_ZYX, out);
 }
 void gpmp2mi_sdf_destroy(gpmp2mi_sdf* s) {
   if (!s) return;

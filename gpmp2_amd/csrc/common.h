@@ -33,6 +33,12 @@ void set_error(const std::string& msg);
     }                               \
   } while (0)
 
+#define G2_TRY(expr)             \
+  do {                           \
+    int rc_ = (expr);            \
+    if (rc_ != GPMP2MI_OK) return rc_; \
+  } while (0)
+
 // ---------------------------------------------------------------- device-side model data
 // Robot model as kernels see it.  Lives in HBM once per robot handle; every workgroup stages it
 // into LDS (3 KB) before use so per-sphere constants are broadcast LDS reads.

@@ -4,6 +4,9 @@
 
 namespace g2 {
 
+// sdf_kernels.hip
+int launch_sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double cell, int* wa, int* wb,
+                              double* field, hipStream_t st);
 // factor_kernels.hip
 int launch_sdf_pack(const SdfDev& s, double* cells, hipStream_t st);
 int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, double* grad, int* inr,

@@ -93,6 +93,46 @@ class Engine:
         h.dim = dim
         return h
 
+    def sdf_field_from_occupancy(self, occ, cell_size):
+        """occupancy [ny][nx] or [nz][ny][nx] -> signed field of the same shape (computed on the GPU)"""
+        occ = f64(occ)
+        dim = occ.ndim
+        nz, ny, nx = ((1,) + occ.shape) if dim == 2 else occ.shape
+        field = np.zeros_like(occ)
+        self._ck(self.lib.gpmp2mi_sdf_field_from_occupancy(C.c_int(dim), nx, ny, nz, dptr(occ), C.c_double(cell_size),
+                                                           dptr(field)))
+        return field
+
+    def sdf_from_occupancy(self, origin, cell_size, occ, layout=_capi.SDF_LAYOUT_ZYX):
+        occ = f64(occ)
+        dim = occ.ndim
+        nz, ny, nx = ((1,) + occ.shape) if dim == 2 else occ.shape
+        org = f64(list(origin) + [0.0] * (3 - len(origin)))
+        out = C.c_void_p()
+        self._ck(self.lib.gpmp2mi_sdf_create_from_occupancy(C.c_int(dim), dptr(org), C.c_double(cell_size), nx, ny, nz,
+                                                            dptr(occ), C.c_int(layout), C.byref(out)))
+        h = _Handle(out, self.lib.gpmp2mi_sdf_destroy)
+        h.dim = dim
+        return h
+
+    def sdf_read_vol(self, filename_pre):
+        out = C.c_void_p()
+        self._ck(self.lib.gpmp2mi_sdf_read_vol(str(filename_pre).encode(), C.byref(out)))
+        h = _Handle(out, self.lib.gpmp2mi_sdf_destroy)
+        h.dim = 3
+        return h
+
+    def sdf_field(self, sdf):
+        """-> dict(dim, origin, cell_size, data [nz][ny][nx] or [ny][nx])"""
+        dim, nx, ny, nz = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        org, cell = np.zeros(3), C.c_double()
+        self._ck(self.lib.gpmp2mi_sdf_get_field(sdf.ptr, C.byref(dim), C.byref(nx), C.byref(ny), C.byref(nz), dptr(org),
+                                                C.byref(cell), None))
+        data = np.zeros((nz.value, ny.value, nx.value))
+        self._ck(self.lib.gpmp2mi_sdf_get_field(sdf.ptr, None, None, None, None, None, None, dptr(data)))
+        return dict(dim=dim.value, origin=org[:dim.value].copy(), cell_size=cell.value,
+                    data=data[0] if dim.value == 2 else data)
+
     # ---------------------------------------------------------------- factor level
     def sdf_query(self, sdf, points):
         p = f64(points).reshape(-1, sdf.dim)

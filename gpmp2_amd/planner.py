@@ -114,6 +114,27 @@ class PlanarSDF(_DeviceSdf):
         return _eng().sdf(self.origin_, self.cell_size_, self.data_)
 
 
+def signedDistanceField2D(ground_truth_map, cell_size):
+    """matlab/+gpmp2/signedDistanceField2D.m:14-34 on the GPU: map [rows = y][cols = x] -> field, same shape"""
+    return _eng().sdf_field_from_occupancy(np.asarray(ground_truth_map, dtype=np.float64), cell_size)
+
+
+def signedDistanceField3D(ground_truth_map, cell_size):
+    """matlab/+gpmp2/signedDistanceField3D.m:14-34 on the GPU: map and field in the dataset's own index
+    order (the transform is symmetric in the axes, so no transpose is needed)"""
+    return _eng().sdf_field_from_occupancy(np.asarray(ground_truth_map, dtype=np.float64), cell_size)
+
+
+def readSDFvolfile(filename_pre):
+    """gpmp2::readSDFvolfile (gpmp2/utils/fileUtils.cpp:17-62) -> SignedDistanceField"""
+    h = _eng().sdf_read_vol(filename_pre)
+    f = _eng().sdf_field(h)
+    sdf = SignedDistanceField(f["origin"], f["cell_size"], f["data"].shape[1], f["data"].shape[2], f["data"].shape[0])
+    sdf.data_ = f["data"]
+    sdf._handle = h
+    return sdf
+
+
 def _robot_handle(model):
     h = getattr(model, "_gpmp2mi_handle", None)
     if h is None:

@@ -106,6 +106,25 @@ int gpmp2mi_sdf_create(int dim, const double origin[3], double cell_size, int nx
                        const double* voxels, int layout, gpmp2mi_sdf** out);
 void gpmp2mi_sdf_destroy(gpmp2mi_sdf* s);
 
+/* Signed distance field from an occupancy grid, on the device
+ * (matlab/+gpmp2/signedDistanceField3D.m:16-34, signedDistanceField2D.m:16-34,
+ * gpmp2_python/utils/signedDistanceField3D.py:22-42): cells with occ > 0.75 are obstacles;
+ * field = (EDT to the obstacle set - EDT to the free set) * cell_size with exact Euclidean
+ * distances; a grid without obstacles (or without free space) gives the constant 1000.
+ * occ, field: host [nz][ny][nx] (nz ignored when dim = 2). */
+int gpmp2mi_sdf_field_from_occupancy(int dim, int nx, int ny, int nz, const double* occ,
+                                     double cell_size, double* field);
+/* same, straight into a field handle (no host round trip of the field); occ in `layout` */
+int gpmp2mi_sdf_create_from_occupancy(int dim, const double origin[3], double cell_size, int nx,
+                                      int ny, int nz, const double* occ, int layout,
+                                      gpmp2mi_sdf** out);
+/* geometry and voxel data ([nz][ny][nx]) of a handle; any output pointer may be NULL */
+int gpmp2mi_sdf_get_field(const gpmp2mi_sdf* s, int* dim, int* nx, int* ny, int* nz,
+                          double origin[3], double* cell_size, double* field);
+/* gpmp2::readSDFvolfile gpmp2/utils/fileUtils.cpp:17-62: "<pre>.vol.head" (cols rows z, origin
+ * xyz, resolution) + "<pre>.vol.data" (text, x outermost, then y, then z) */
+int gpmp2mi_sdf_read_vol(const char* filename_pre, gpmp2mi_sdf** out);
+
 /* SignedDistanceField::getSignedDistance(point, g) obstacle/SignedDistanceField.h:93-99 and
  * PlanarSDF::getSignedDistance obstacle/PlanarSDF.h:61-68, batched over M points.
  * points [M][dim]; dist [M]; grad [M][dim] or NULL; in_range [M] or NULL

@@ -6,6 +6,7 @@
 //   gpmp2::TrajOptimizerSetting                         gpmp2/planner/TrajOptimizerSetting.h:17-100
 //   gpmp2::BatchTrajOptimize3DArm / 2DArm               gpmp2/planner/BatchTrajOptimizer.h:43-56
 //   gpmp2::CollisionCost3DArm / 2DArm                   gpmp2/planner/BatchTrajOptimizer.h:135-147
+//   gpmp2::interpolateArmTraj / interpolatePose2MobileArmTraj  gpmp2/planner/TrajUtils.cpp:96-236
 //   gpmp2::ISAM2TrajOptimizer2DArm / 3DArm              gpmp2/planner/ISAM2TrajOptimizer.h:143-156
 //   gpmp2::initArmTrajStraightLine                      gpmp2/planner/TrajUtils.cpp:25-50
 //
@@ -344,6 +345,37 @@ inline double CollisionCost2DArm(const ArmModel& arm, const PlanarSDF& sdf, cons
   check(gpmp2mi_collision_cost(arm.handle(), sdf.handle(), static_cast<int>(result.total_step), 1, result.data.data(), &c),
         "gpmp2mi_collision_cost");
   return c;
+}
+
+namespace internal {
+inline Trajectory interpolateTraj(const Trajectory& opt_values, const Vector& Qc, double delta_t, std::size_t inter_step,
+                                  std::size_t start_index, std::size_t end_index, bool lie) {
+  if (!Qc.empty() && Qc.size() != opt_values.dof * opt_values.dof)
+    throw std::runtime_error("[interpolateArmTraj] Qc dim does not fit dof");
+  if (start_index >= end_index || end_index > opt_values.total_step)
+    throw std::runtime_error("[interpolateArmTraj] need start_index < end_index <= total_step");
+  Trajectory out(opt_values.dof, (end_index - start_index) * (inter_step + 1));
+  check(gpmp2mi_interpolate_traj(static_cast<int>(opt_values.dof), lie ? 1 : 0, Qc.empty() ? nullptr : Qc.data(), delta_t,
+                                 static_cast<int>(inter_step), 1, static_cast<int>(opt_values.total_step),
+                                 static_cast<int>(start_index), static_cast<int>(end_index), opt_values.data.data(),
+                                 out.data.data()),
+        "gpmp2mi_interpolate_traj");
+  return out;
+}
+}  // namespace internal
+/// gpmp2::interpolateArmTraj  gpmp2/planner/TrajUtils.cpp:96-159 (Qc row-major [dof][dof], may be empty)
+inline Trajectory interpolateArmTraj(const Trajectory& opt_values, const Vector& Qc, double delta_t, std::size_t inter_step) {
+  return internal::interpolateTraj(opt_values, Qc, delta_t, inter_step, 0, opt_values.total_step, false);
+}
+/// gpmp2::interpolateArmTraj with a state range  gpmp2/planner/TrajUtils.cpp:162-197
+inline Trajectory interpolateArmTraj(const Trajectory& opt_values, const Vector& Qc, double delta_t, std::size_t inter_step,
+                                     std::size_t start_index, std::size_t end_index) {
+  return internal::interpolateTraj(opt_values, Qc, delta_t, inter_step, start_index, end_index, false);
+}
+/// gpmp2::interpolatePose2MobileArmTraj  gpmp2/planner/TrajUtils.cpp:200-236 (states [x, y, theta, q...])
+inline Trajectory interpolatePose2MobileArmTraj(const Trajectory& opt_values, const Vector& Qc, double delta_t,
+                                                std::size_t inter_step, std::size_t start_index, std::size_t end_index) {
+  return internal::interpolateTraj(opt_values, Qc, delta_t, inter_step, start_index, end_index, true);
 }
 
 namespace internal {

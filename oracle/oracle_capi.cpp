@@ -119,6 +119,11 @@ int orc_sdf_create(int dim, const double* origin, double cell, int nx, int ny, i
 }
 void orc_sdf_destroy(void* s) { delete (Sdf*)s; }
 
+int orc_sdf_field_from_occupancy(int dim, int nx, int ny, int nz, const double* occ, double cell, double* field) {
+  sdf_from_occupancy(nx, ny, dim == 3 ? nz : 1, occ, cell, field);
+  return 0;
+}
+
 int orc_sdf_query(const void* s_, int M, const double* pts, double* dist, double* grad, int* inr) {
   const Sdf& s = *(const Sdf*)s_;
   for (int m = 0; m < M; m++) {

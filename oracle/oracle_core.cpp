@@ -224,6 +224,55 @@ void pose2_logmap_derivative(const Pose2& p, double J[9]) {
   }
 }
 
+// =============================================================================== SDF construction
+// matlab/+gpmp2/signedDistanceField3D.m:16-34 (bwdist) / gpmp2_python/utils/signedDistanceField3D.py:22-42
+// (scipy.ndimage.distance_transform_edt): exact Euclidean distance to the nearest cell of the
+// other class.  Restated as the textbook separable minimisation of integer squared distances
+//   d2(p) = min_q |p - q|^2  =  min_z' ( min_y' ( min_x' [q in set] ) + (y-y')^2 ) + (z-z')^2
+// evaluated by plain loops (test sizes only).
+static void edt_axis(std::vector<long long>& v, size_t outer, size_t len, size_t inner) {
+  std::vector<long long> line(len);
+  for (size_t o = 0; o < outer; o++)
+    for (size_t in = 0; in < inner; in++) {
+      long long* g = v.data() + o * len * inner + in;
+      for (size_t j = 0; j < len; j++) line[j] = g[j * inner];
+      for (size_t i = 0; i < len; i++) {
+        long long best = line[i];
+        for (size_t j = 0; j < len; j++) {
+          const long long dd = (long long)i - (long long)j;
+          best = std::min(best, line[j] + dd * dd);
+        }
+        g[i * inner] = best;
+      }
+    }
+}
+void sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double cell, double* field) {
+  const size_t n = (size_t)nx * ny * nz;
+  const long long INF = 1ll << 40;
+  std::vector<long long> a(n), b(n);
+  bool any_obst = false, any_free = false;
+  for (size_t i = 0; i < n; i++) {
+    const bool obst = occ[i] > 0.75;
+    a[i] = obst ? 0 : INF;
+    b[i] = obst ? INF : 0;
+    any_obst |= obst;
+    any_free |= !obst;
+  }
+  if (!any_obst || !any_free) {  // bwdist gives Inf -> "limit inf" branch, signedDistanceField3D.m:30-33
+    for (size_t i = 0; i < n; i++) field[i] = 1000.0;
+    return;
+  }
+  for (auto* v : {&a, &b}) {
+    edt_axis(*v, (size_t)ny * nz, nx, 1);
+    edt_axis(*v, nz, ny, nx);
+    edt_axis(*v, 1, nz, (size_t)nx * ny);
+  }
+  for (size_t i = 0; i < n; i++) {
+    const double map_dist = std::sqrt((double)a[i]), inv_map_dist = std::sqrt((double)b[i]);
+    field[i] = (map_dist - inv_map_dist) * cell;
+  }
+}
+
 // =============================================================================== 4x4 helpers
 static void m4mul(const double* A, const double* B, double* C) {
   double T[16];

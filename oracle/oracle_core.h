@@ -64,6 +64,9 @@ struct Sdf {
   double at(int row, int col, int z) const { return v[((size_t)z * ny + row) * nx + col]; }
 };
 
+// signed field of an occupancy grid (matlab/+gpmp2/signedDistanceField3D.m:16-34): occ, field [nz][ny][nx]
+void sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double cell, double* field);
+
 // ---------------------------------------------------------------- GP (gpmp2/gp/GPutils.h)
 Mat calcQ(const Mat& Qc, double tau);
 Mat calcQ_inv(const Mat& Qc, double tau);

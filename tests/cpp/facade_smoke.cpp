@@ -35,6 +35,9 @@ int main() {
     const Trajectory out = BatchTrajOptimize2DArm(model, sdf, start, zero, end, zero, init, setting, &iters, &err);
     std::printf("OK iterations=%d final_error=%.6f x_5=(%.4f, %.4f) collision=%.4f\n", iters, err, out.x(5)[0],
                 out.x(5)[1], CollisionCost2DArm(model, sdf, out, setting));
+    const Trajectory dense = interpolateArmTraj(out, {}, 0.2, 4);
+    if (dense.total_step != 50 || std::fabs(dense.x(50)[0] - out.x(10)[0]) > 0 || std::fabs(dense.x(5)[1] - out.x(1)[1]) > 0) return 5;
+    std::printf("DENSE states=%zu x_27=(%.4f, %.4f)\n", dense.total_step + 1, dense.x(27)[0], dense.x(27)[1]);
     // replanner: batch answer as initial values, fix state 3 where it is, move the goal, two updates
     ISAM2TrajOptimizer2DArm isam(model, sdf, setting);
     isam.initFactorGraph(start, zero, end, zero);

@@ -70,6 +70,14 @@ class Oracle:
         return h
 
     # ---------------------------------------------------------------- factor level
+    def sdf_field_from_occupancy(self, occ, cell_size):
+        occ = f64(occ)
+        dim = occ.ndim
+        nz, ny, nx = ((1,) + occ.shape) if dim == 2 else occ.shape
+        field = np.zeros_like(occ)
+        self.lib.orc_sdf_field_from_occupancy(C.c_int(dim), nx, ny, nz, dptr(occ), C.c_double(cell_size), dptr(field))
+        return field
+
     def sdf_query(self, sdf, points):
         p = f64(points).reshape(-1, sdf.dim)
         M = p.shape[0]

@@ -219,3 +219,57 @@ def test_empty_batches_and_bad_arguments(engine):
     bad.spheres[0].link_id = 5
     with pytest.raises(Gpmp2miError):
         engine.robot(bad)
+
+
+# ------------------------------------------------------------------ SDF construction on the device
+@pytest.mark.parametrize("shape", [(17, 23), (6, 9, 11), (1, 7), (5, 1, 8), (3, 70, 130), (150, 3)])
+def test_sdf_from_occupancy_bit_exact(engine, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    occ = (rng.uniform(size=shape) > 0.9).astype(float)
+    np.testing.assert_array_equal(engine.sdf_field_from_occupancy(occ, 0.05), oracle.sdf_field_from_occupancy(occ, 0.05))
+    for deg in (np.zeros(shape), np.ones(shape)):
+        np.testing.assert_array_equal(engine.sdf_field_from_occupancy(deg, 0.05), 1000.0 * np.ones(shape))
+
+
+def test_sdf_from_occupancy_full_size_datasets(engine):
+    """full-size maps of the reference's examples against the scipy transform its python utilities use"""
+    import gpmp2_amd as g
+    d2 = g.generate2Ddataset("MobileMap1")
+    np.testing.assert_array_equal(engine.sdf_field_from_occupancy(d2.map, d2.cell_size),
+                                  g.datasets.signedDistanceField2D(d2.map, d2.cell_size))
+    d3 = g.generate3Ddataset("WAMDeskDataset")
+    occ = g.sdf3_zyx(d3.map)
+    want = g.sdf3_zyx(g.datasets.signedDistanceField3D(d3.map, d3.cell_size))
+    np.testing.assert_array_equal(engine.sdf_field_from_occupancy(occ, d3.cell_size), want)
+    # straight into a handle: same lookups as a handle built from the host field
+    org = [d3.origin_x, d3.origin_y, d3.origin_z]
+    a = engine.sdf_from_occupancy(org, d3.cell_size, occ)
+    b = engine.sdf(org, d3.cell_size, want)
+    pts = np.random.default_rng(0).uniform(-0.4, 0.4, size=(500, 3)) + np.array(org) + 0.5 * d3.cell_size * np.array(occ.shape[::-1])
+    for x, y in zip(engine.sdf_query(a, pts), engine.sdf_query(b, pts)):
+        np.testing.assert_array_equal(x, y)
+    got = engine.sdf_field(a)
+    assert got["dim"] == 3 and got["cell_size"] == d3.cell_size
+    np.testing.assert_array_equal(got["data"], want)
+
+
+def test_sdf_read_vol(engine, tmp_path):
+    """readSDFvolfile (gpmp2/utils/fileUtils.cpp:17-62): head = cols rows z / origin / resolution,
+    data = text with x outermost, then y, then z"""
+    rng = np.random.default_rng(3)
+    nx, ny, nz = 4, 3, 5
+    field = rng.normal(size=(nz, ny, nx)).round(6)
+    pre = tmp_path / "scene"
+    (tmp_path / "scene.vol.head").write_text(f"{nx} {ny} {nz}\n-1.0 -0.5 0.25\n0.1\n")
+    (tmp_path / "scene.vol.data").write_text(" ".join(f"{field[z, y, x]:.6f}" for x in range(nx) for y in range(ny) for z in range(nz)))
+    h = engine.sdf_read_vol(pre)
+    got = engine.sdf_field(h)
+    np.testing.assert_array_equal(got["data"], field)
+    np.testing.assert_array_equal(got["origin"], [-1.0, -0.5, 0.25])
+    assert got["cell_size"] == 0.1
+    with pytest.raises(Exception):
+        engine.sdf_read_vol(tmp_path / "missing")
+    (tmp_path / "short.vol.head").write_text(f"{nx} {ny} {nz}\n0 0 0\n0.1\n")
+    (tmp_path / "short.vol.data").write_text("1.0 2.0")
+    with pytest.raises(Exception):
+        engine.sdf_read_vol(tmp_path / "short")

@@ -68,6 +68,22 @@ def test_sdf_classes(engine, golden):
         assert abs(psdf.getSignedDistance(q["point"]) - q["value"]) <= q["tol"]
 
 
+def test_signed_distance_field_functions_and_vol_reader(engine, tmp_path):
+    d = g.generate2Ddataset("OneObstacleDataset")
+    np.testing.assert_array_equal(g.signedDistanceField2D(d.map, d.cell_size), g.datasets.signedDistanceField2D(d.map, d.cell_size))
+    rng = np.random.default_rng(2)
+    m3 = (rng.uniform(size=(12, 9, 7)) > 0.85).astype(float)
+    np.testing.assert_array_equal(g.signedDistanceField3D(m3, 0.1), g.datasets.signedDistanceField3D(m3, 0.1))
+    field = g.sdf3_zyx(g.signedDistanceField3D(m3, 0.1))                  # [z][y][x]
+    nz, ny, nx = field.shape
+    (tmp_path / "m.vol.head").write_text(f"{nx} {ny} {nz}\n0 0 0\n0.1\n")
+    (tmp_path / "m.vol.data").write_text("\n".join(repr(float(field[z, y, x])) for x in range(nx) for y in range(ny) for z in range(nz)))
+    sdf = g.readSDFvolfile(tmp_path / "m")
+    assert (sdf.x_count(), sdf.y_count(), sdf.z_count()) == (nx, ny, nz)
+    np.testing.assert_array_equal(sdf.raw_data(), field)
+    assert abs(sdf.getSignedDistance([0.3, 0.2, 0.1]) - field[1, 2, 3]) < 1e-9
+
+
 # ------------------------------------------------------------------ WAMPlannerExample-like flow
 def _wam(total_step=10):
     p = problems.wam_restarts(B=1, total_step=total_step, obs_check_inter=4, sdf="40")

@@ -439,3 +439,26 @@ def test_host_pose2_helpers_match_oracle(oracle):
         np.testing.assert_allclose(tu.pose2_expmap(v), p, atol=1e-14)
         np.testing.assert_allclose(tu.pose2_logmap(p), oracle.pose2_logmap(p), atol=1e-13)
     np.testing.assert_allclose(tu.pose2_expmap(np.array([0.3, -0.2, 0.0])), [0.3, -0.2, 0.0])
+
+
+# ------------------------------------------------------------------ SDF construction (signedDistanceField{2D,3D})
+@pytest.mark.parametrize("shape", [(17, 23), (6, 9, 11), (1, 7), (5, 1, 8)])
+def test_sdf_from_occupancy_matches_scipy_edt(oracle, shape):
+    """the reference's python utilities call scipy.ndimage.distance_transform_edt
+    (gpmp2_python/utils/signedDistanceField3D.py:22-42); the restated transform must agree bit for bit"""
+    from scipy import ndimage
+    rng = np.random.default_rng(sum(shape))
+    occ = (rng.uniform(size=shape) > 0.8).astype(float)
+    occ[tuple(0 for _ in shape)] = 0.6            # "unknown" cells count as free (threshold 0.75)
+    cur = occ > 0.75
+    expect = (ndimage.distance_transform_edt(~cur) - ndimage.distance_transform_edt(cur)) * 0.05
+    np.testing.assert_array_equal(oracle.sdf_field_from_occupancy(occ, 0.05), expect)
+    np.testing.assert_array_equal(g.datasets._signed_distance(occ, 0.05), expect)
+
+
+def test_sdf_from_occupancy_degenerate_maps(oracle):
+    for occ in (np.zeros((4, 5)), np.ones((3, 4, 5))):
+        np.testing.assert_array_equal(oracle.sdf_field_from_occupancy(occ, 0.1), 1000.0 * np.ones(occ.shape))
+    d = g.generate2Ddataset("OneObstacleDataset")
+    np.testing.assert_array_equal(oracle.sdf_field_from_occupancy(d.map, d.cell_size),
+                                  g.datasets.signedDistanceField2D(d.map, d.cell_size))
