@@ -536,6 +536,65 @@ int gpmp2mi_sphere_centers(const gpmp2mi_robot* r, int M, const double* conf, do
   return GPMP2MI_OK;
 }
 
+int gpmp2mi_workspace_prior_factor(const gpmp2mi_robot* r, int mode, int joint, const double des_pose[16], int M,
+                                   const double* conf, double* err, double* H) {
+  G2_CHECK(r && des_pose && conf && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(mode >= GPMP2MI_WORKSPACE_POSITION && mode <= GPMP2MI_WORKSPACE_POSE, GPMP2MI_ERR_INVALID, "unknown mode");
+  G2_CHECK(joint >= 0 && joint < r->h.nr_links, GPMP2MI_ERR_INVALID, "joint out of range");
+  if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  const int D = r->h.dof, L = r->h.nr_links, rows = mode == GPMP2MI_WORKSPACE_POSE ? 6 : 3;
+  DevBuf<double> dq, dp, dj, dd, de, dh;
+  G2_TRY(dq.upload(conf, (size_t)M * D));
+  G2_TRY(dd.upload(des_pose, 16));
+  G2_TRY(dp.alloc((size_t)M * L * 16));
+  if (H) G2_TRY(dj.alloc((size_t)M * L * 6 * D));
+  G2_TRY(de.alloc((size_t)M * rows));
+  if (H) G2_TRY(dh.alloc((size_t)M * rows * D));
+  G2_TRY(launch_fk(r->h, r->d, M, dq.p, dp.p, dj.p, nullptr));
+  G2_TRY(launch_workspace_prior(mode, joint, L, D, M, dd.p, dp.p, dj.p, de.p, dh.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(dh.download(H));
+  return GPMP2MI_OK;
+}
+
+int gpmp2mi_goal_factor_arm(const gpmp2mi_robot* r, const double dest_point[3], int M, const double* conf, double* err,
+                            double* H) {
+  G2_CHECK(r && dest_point, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(r->h.kind == GPMP2MI_ROBOT_ARM, GPMP2MI_ERR_INVALID, "GoalFactorArm needs an Arm");
+  const double des[16] = {1, 0, 0, dest_point[0], 0, 1, 0, dest_point[1], 0, 0, 1, dest_point[2], 0, 0, 0, 1};
+  return gpmp2mi_workspace_prior_factor(r, GPMP2MI_WORKSPACE_POSITION, r->h.arm_dof - 1, des, M, conf, err, H);
+}
+
+int gpmp2mi_self_collision_factor(const gpmp2mi_robot* r, int n_pairs, const double* data, int M, const double* conf,
+                                  double* err, double* H) {
+  G2_CHECK(r && data && conf && err && M >= 0 && n_pairs >= 0, GPMP2MI_ERR_INVALID, "null argument");
+  const int D = r->h.dof, S = r->h.nr_spheres;
+  for (int i = 0; i < n_pairs; i++) {
+    const double a = data[i * 4], b = data[i * 4 + 1];
+    G2_CHECK(a >= 0 && a < S && b >= 0 && b < S, GPMP2MI_ERR_INVALID, "sphere id out of range");
+  }
+  if (M == 0 || n_pairs == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  std::vector<double> radius(S);
+  for (int s = 0; s < S; s++) radius[r->h.sph_orig[s]] = r->h.sph_r[s];
+  DevBuf<double> dq, dc, dj, dd, dr, de, dh;
+  G2_TRY(dq.upload(conf, (size_t)M * D));
+  G2_TRY(dd.upload(data, (size_t)n_pairs * 4));
+  G2_TRY(dr.upload(radius.data(), S));
+  G2_TRY(dc.alloc((size_t)M * S * 3));
+  if (H) G2_TRY(dj.alloc((size_t)M * S * 3 * D));
+  G2_TRY(de.alloc((size_t)M * n_pairs));
+  if (H) G2_TRY(dh.alloc((size_t)M * n_pairs * D));
+  G2_TRY(launch_sphere_centers(r->h, r->d, M, dq.p, dc.p, dj.p, nullptr));
+  G2_TRY(launch_self_collision(n_pairs, S, D, M, dd.p, dr.p, dc.p, dj.p, de.p, dh.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(dh.download(H));
+  return GPMP2MI_OK;
+}
+
 int gpmp2mi_obstacle_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, double eps, int M,
                             const double* conf, double* err, double* H1) {
   G2_CHECK(r && s && conf && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");

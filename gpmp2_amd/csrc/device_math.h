@@ -154,44 +154,41 @@ struct Kin {
   static constexpr int NLINKS = (KIND == GPMP2MI_ROBOT_ARM) ? AD
                                 : (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? AD + 1 : 1;
 
-  // Visitor over the body spheres (sorted by link):
-  //   pre(s, p) -> bool      : called with the sphere centre; return true if the Jacobian is wanted
-  //   post(s, p, J, nc)      : J[k] = d p / d q_k for k < nc (compile-time integral_constant nc),
-  //                            zero for k >= nc -- spheres on link j only depend on the first joints
-  // sub / nsub: visit only the spheres s with s % nsub == sub (lane-split kernels); nsub a power of 2.
-  template <class Pre, class Post>
-  __device__ __forceinline__ static void visit_spheres(const RobotDev& R, const double (&q)[DOF], Pre&& pre,
-                                                       Post&& post, int sub = 0, int nsub = 1) {
-    const int smask = nsub - 1;
-    double J[DOF][3];
-#pragma unroll
-    for (int k = 0; k < DOF; k++) J[k][0] = J[k][1] = J[k][2] = 0.0;
+  // Joint axes / origins of one configuration: all a sphere Jacobian needs besides the sphere centre.
+  struct Axes {
+    double zax[AD > 0 ? AD : 1][3], org[AD > 0 ? AD : 1][3];
+    double vt[3], bx[3], by[3];  // vehicle origin and heading columns (mobile robots)
+  };
 
+  // Walk the kinematic chain once: f(s, p, nc) for every body sphere in sorted order, with its world
+  // centre p and nc = integral_constant<number of leading non-zero Jacobian columns>; fills A on the way
+  // (A.zax[k], A.org[k] are valid for k < nc - BASE when f is called).
+  // sub / nsub: visit only the spheres s with s % nsub == sub (lane-split kernels); nsub a power of 2.
+  template <class F>
+  __device__ __forceinline__ static void walk(const RobotDev& R, const double (&q)[DOF], Axes& A, F&& f,
+                                              int sub = 0, int nsub = 1) {
+    const int smask = nsub - 1;
     if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
       // PointRobot::forwardKinematics  kinematics/PointRobot.cpp:15-49
-      J[0][0] = 1.0;
-      J[1][1] = 1.0;
       for (int s = 0; s < R.nr_spheres; s++) {
         if ((s & smask) != sub) continue;
-        double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
-        if (pre(s, p)) post(s, p, J, std::integral_constant<int, 2>{});
+        const double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
+        f(s, p, std::integral_constant<int, 2>{});
       }
-      return;
     } else {
       Frame Fr;
-      double vt[3] = {0, 0, 0};  // vehicle origin (mobile robots)
+      A.vt[0] = A.vt[1] = A.vt[2] = 0.0;
       if constexpr (BASE == 3) {
         // computeBasePose3  kinematics/mobileBaseUtils.cpp:18-31
-        double s, c;
-        sincos(q[2], &s, &c);
-        Fr.c0[0] = c; Fr.c0[1] = s; Fr.c0[2] = 0;
-        Fr.c1[0] = -s; Fr.c1[1] = c; Fr.c1[2] = 0;
+        double sn, c;
+        sincos(q[2], &sn, &c);
+        Fr.c0[0] = c; Fr.c0[1] = sn; Fr.c0[2] = 0;
+        Fr.c1[0] = -sn; Fr.c1[1] = c; Fr.c1[2] = 0;
         Fr.c2[0] = 0; Fr.c2[1] = 0; Fr.c2[2] = 1;
         Fr.t[0] = q[0]; Fr.t[1] = q[1]; Fr.t[2] = 0;
-        vt[0] = q[0]; vt[1] = q[1];
-        const double bx[3] = {c, s, 0}, by[3] = {-s, c, 0};
-#pragma unroll
-        for (int i = 0; i < 3; i++) { J[0][i] = bx[i]; J[1][i] = by[i]; }
+        A.vt[0] = q[0]; A.vt[1] = q[1];
+        A.bx[0] = c; A.bx[1] = sn; A.bx[2] = 0;
+        A.by[0] = -sn; A.by[1] = c; A.by[2] = 0;
         // link 0 = vehicle base
         for (int s0 = R.link_first[0]; s0 < R.link_first[1]; s0++) {
           if ((s0 & smask) != sub) continue;
@@ -200,11 +197,7 @@ struct Kin {
           for (int i = 0; i < 3; i++)
             p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s0] + Fr.c1[i] * R.sph_c[3 * s0 + 1] +
                    Fr.c2[i] * R.sph_c[3 * s0 + 2];
-          if (!pre(s0, p)) continue;
-          J[2][0] = -(p[1] - vt[1]);  // z x (p - t_veh)
-          J[2][1] = (p[0] - vt[0]);
-          J[2][2] = 0.0;
-          post(s0, p, J, std::integral_constant<int, 3>{});
+          f(s0, p, std::integral_constant<int, 3>{});
         }
         if constexpr (AD > 0) {
           // arm base = veh * base_T_arm  (computeBaseTransPose3, mobileBaseUtils.cpp:34-48)
@@ -224,13 +217,12 @@ struct Kin {
         frame_from_3x4(R.base, Fr);
       }
       if constexpr (AD > 0) {
-        double zax[AD][3], org[AD][3];
         static_for<0, AD>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
 #pragma unroll
           for (int i = 0; i < 3; i++) {
-            zax[j][i] = Fr.c2[i];
-            org[j][i] = Fr.t[i];
+            A.zax[j][i] = Fr.c2[i];
+            A.org[j][i] = Fr.t[i];
           }
           dh_advance(Fr, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
           constexpr int link = (BASE == 3) ? j + 1 : j;
@@ -241,24 +233,69 @@ struct Kin {
             for (int i = 0; i < 3; i++)
               p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s] + Fr.c1[i] * R.sph_c[3 * s + 1] +
                      Fr.c2[i] * R.sph_c[3 * s + 2];
-            if (!pre(s, p)) continue;
-            if constexpr (BASE == 3) {
-              J[2][0] = -(p[1] - vt[1]);
-              J[2][1] = (p[0] - vt[0]);
-              J[2][2] = 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k <= j; k++) {
-              const double rx = p[0] - org[k][0], ry = p[1] - org[k][1], rz = p[2] - org[k][2];
-              J[BASE + k][0] = zax[k][1] * rz - zax[k][2] * ry;
-              J[BASE + k][1] = zax[k][2] * rx - zax[k][0] * rz;
-              J[BASE + k][2] = zax[k][0] * ry - zax[k][1] * rx;
-            }
-            post(s, p, J, std::integral_constant<int, BASE + j + 1>{});
+            f(s, p, std::integral_constant<int, BASE + j + 1>{});
           }
         });
       }
     }
+  }
+
+  // Jacobian columns of a sphere centre p from the axes of the walk: J[k] = d p / d q_k for k < NC
+  // (columns >= NC are not touched).  Column k of an arm joint = z_k x (p - o_k).
+  template <int NC>
+  __device__ __forceinline__ static void jacobian(const Axes& A, const double (&p)[3], std::integral_constant<int, NC>,
+                                                  double (&J)[DOF][3]) {
+    if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
+      J[0][0] = 1.0; J[0][1] = 0.0; J[0][2] = 0.0;
+      J[1][0] = 0.0; J[1][1] = 1.0; J[1][2] = 0.0;
+    } else {
+      if constexpr (BASE == 3) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { J[0][i] = A.bx[i]; J[1][i] = A.by[i]; }
+        J[2][0] = -(p[1] - A.vt[1]);  // z x (p - t_veh)
+        J[2][1] = (p[0] - A.vt[0]);
+        J[2][2] = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < NC - BASE; k++) {
+        const double rx = p[0] - A.org[k][0], ry = p[1] - A.org[k][1], rz = p[2] - A.org[k][2];
+        J[BASE + k][0] = A.zax[k][1] * rz - A.zax[k][2] * ry;
+        J[BASE + k][1] = A.zax[k][2] * rx - A.zax[k][0] * rz;
+        J[BASE + k][2] = A.zax[k][0] * ry - A.zax[k][1] * rx;
+      }
+    }
+  }
+
+  // f(s, nc) for every sphere in sorted order with its compile-time column count (no kinematics)
+  template <class F>
+  __device__ __forceinline__ static void each_sphere(const RobotDev& R, F&& f) {
+    if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
+      for (int s = 0; s < R.nr_spheres; s++) f(s, std::integral_constant<int, 2>{});
+    } else {
+      static_for<0, NLINKS>([&](auto lc) {
+        constexpr int link = decltype(lc)::value;
+        constexpr int NC = (BASE == 3) ? 3 + link : link + 1;
+        for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) f(s, std::integral_constant<int, NC>{});
+      });
+    }
+  }
+
+  // Visitor over the body spheres (sorted by link):
+  //   pre(s, p) -> bool      : called with the sphere centre; return true if the Jacobian is wanted
+  //   post(s, p, J, nc)      : J[k] = d p / d q_k for k < nc (compile-time integral_constant nc),
+  //                            zero for k >= nc -- spheres on link j only depend on the first joints
+  template <class Pre, class Post>
+  __device__ __forceinline__ static void visit_spheres(const RobotDev& R, const double (&q)[DOF], Pre&& pre,
+                                                       Post&& post, int sub = 0, int nsub = 1) {
+    Axes A;
+    double J[DOF][3];
+#pragma unroll
+    for (int k = 0; k < DOF; k++) J[k][0] = J[k][1] = J[k][2] = 0.0;
+    walk(R, q, A, [&](int s, const double (&p)[3], auto nc) {
+      if (!pre(s, p)) return;
+      jacobian(A, p, nc, J);
+      post(s, p, J, nc);
+    }, sub, nsub);
   }
 
   // simple form: f(sorted_index, p[3], Jcol[DOF][3], ncols) for every sphere

@@ -458,6 +458,216 @@ __global__ void k_interpolate_traj(double dt, int inter, int B, int N, int start
   }
 }
 
+// --------------------------------------------------------------------------- SO(3) / SE(3) logs
+// GTSAM 4.0 semantics (upstream, restated): SO3::Logmap / LogmapDerivative, Pose3::Logmap /
+// LogmapDerivative with Barfoot's Q matrix.  Used by the workspace priors below.
+__device__ __forceinline__ void skew3(const double* w, double* W) {
+  W[0] = 0; W[1] = -w[2]; W[2] = w[1];
+  W[3] = w[2]; W[4] = 0; W[5] = -w[0];
+  W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
+}
+__device__ __forceinline__ void rot3_logmap(const double* R, double* w) {
+  const double R11 = R[0], R12 = R[1], R13 = R[2], R21 = R[3], R22 = R[4], R23 = R[5], R31 = R[6], R32 = R[7], R33 = R[8];
+  const double tr = R11 + R22 + R33;
+  constexpr double kPi = 3.14159265358979323846;
+  if (fabs(tr + 1.0) < 1e-10) {
+    if (fabs(R33 + 1.0) > 1e-10) {
+      const double k = kPi / sqrt(2.0 + 2.0 * R33);
+      w[0] = k * R13; w[1] = k * R23; w[2] = k * (1.0 + R33);
+    } else if (fabs(R22 + 1.0) > 1e-10) {
+      const double k = kPi / sqrt(2.0 + 2.0 * R22);
+      w[0] = k * R12; w[1] = k * (1.0 + R22); w[2] = k * R32;
+    } else {
+      const double k = kPi / sqrt(2.0 + 2.0 * R11);
+      w[0] = k * (1.0 + R11); w[1] = k * R21; w[2] = k * R31;
+    }
+  } else {
+    double magnitude;
+    const double tr_3 = tr - 3.0;
+    if (tr_3 < -1e-7) {
+      const double theta = acos((tr - 1.0) / 2.0);
+      magnitude = theta / (2.0 * sin(theta));
+    } else {
+      magnitude = 0.5 - tr_3 * tr_3 / 12.0;
+    }
+    w[0] = magnitude * (R32 - R23);
+    w[1] = magnitude * (R13 - R31);
+    w[2] = magnitude * (R21 - R12);
+  }
+}
+__device__ __forceinline__ void rot3_logmap_derivative(const double* w, double* H) {
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  for (int i = 0; i < 9; i++) H[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (theta2 <= 2.220446049250313e-16) return;
+  const double theta = sqrt(theta2);
+  double W[9], WW[9];
+  skew3(w, W);
+  mat3_mul(W, W, WW);
+  const double k = 1.0 / (theta * theta) - (1.0 + cos(theta)) / (2.0 * theta * sin(theta));
+  for (int i = 0; i < 9; i++) H[i] += 0.5 * W[i] + k * WW[i];
+}
+__device__ __forceinline__ void pose3_logmap(const double* R, const double* T, double* xi) {
+  double w[3];
+  rot3_logmap(R, w);
+  const double t = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (t < 1e-10) {
+    xi[3] = T[0]; xi[4] = T[1]; xi[5] = T[2];
+    return;
+  }
+  const double wn[3] = {w[0] / t, w[1] / t, w[2] / t};
+  double W[9], WT[3], WWT[3];
+  skew3(wn, W);
+  const double Tan = tan(0.5 * t);
+  for (int i = 0; i < 3; i++) WT[i] = W[i * 3] * T[0] + W[i * 3 + 1] * T[1] + W[i * 3 + 2] * T[2];
+  for (int i = 0; i < 3; i++) WWT[i] = W[i * 3] * WT[0] + W[i * 3 + 1] * WT[1] + W[i * 3 + 2] * WT[2];
+  for (int i = 0; i < 3; i++) xi[3 + i] = T[i] - (0.5 * t) * WT[i] + (1.0 - t / (2.0 * Tan)) * WWT[i];
+}
+__device__ __forceinline__ void pose3_logmap_derivative(const double* R, const double* T, double* H) {
+  double xi[6], Jw[9], Q[9], Q2[9];
+  pose3_logmap(R, T, xi);
+  rot3_logmap_derivative(xi, Jw);
+  {
+    double V[9], W[9], WV[9], VW[9], WVW[9], WW[9], WWV[9], VWW[9], WVWW[9], WWVW[9];
+    skew3(xi + 3, V);
+    skew3(xi, W);
+    mat3_mul(W, V, WV);
+    mat3_mul(V, W, VW);
+    mat3_mul(WV, W, WVW);
+    mat3_mul(W, W, WW);
+    mat3_mul(WW, V, WWV);
+    mat3_mul(VW, W, VWW);
+    mat3_mul(WVW, W, WVWW);
+    mat3_mul(W, WVW, WWVW);
+    const double phi = sqrt(xi[0] * xi[0] + xi[1] * xi[1] + xi[2] * xi[2]);
+    double c1, c2, c3;
+    if (fabs(phi) > 1e-5) {
+      const double sn = sin(phi), c = cos(phi);
+      const double phi2 = phi * phi, phi3 = phi2 * phi, phi4 = phi3 * phi, phi5 = phi4 * phi;
+      c1 = (phi - sn) / phi3;
+      c2 = (1.0 - phi2 / 2.0 - c) / phi4;
+      c3 = -0.5 * ((1.0 - phi2 / 2.0 - c) / phi4 - 3.0 * (phi - sn - phi3 / 6.0) / phi5);
+    } else {
+      c1 = 1.0 / 6.0;
+      c2 = 1.0 / 24.0;
+      c3 = -0.5 * (1.0 / 24.0 + 3.0 / 120.0);
+    }
+    for (int i = 0; i < 9; i++)
+      Q[i] = -0.5 * V[i] + c1 * (WV[i] + VW[i] - WVW[i]) + c2 * (WWV[i] + VWW[i] - 3.0 * WVW[i]) + c3 * (WVWW[i] + WWVW[i]);
+  }
+  mat3_mul(Jw, Q, Q2);
+  double Q3[9];
+  mat3_mul(Q2, Jw, Q3);
+  for (int i = 0; i < 36; i++) H[i] = 0.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      H[i * 6 + j] = Jw[i * 3 + j];
+      H[(3 + i) * 6 + 3 + j] = Jw[i * 3 + j];
+      H[(3 + i) * 6 + j] = -Q3[i * 3 + j];
+    }
+}
+
+// GaussianPriorWorkspace{Position,Orientation,Pose}::evaluateError and GoalFactorArm::evaluateError
+// (kinematics/GaussianPriorWorkspacePosition.h:52-67, ...Orientation.h:52-69, ...Pose.h:53-70,
+// kinematics/GoalFactorArm.h:58-77) on the link poses / pose Jacobians k_fk produced:
+// poses [M][L][16], Jp [M][L][6][D]; err [M][rows], H [M][rows][D] (may be null)
+__global__ void k_workspace_prior(int mode, int joint, int L, int D, int M, const double* __restrict__ des,
+                                  const double* __restrict__ poses, const double* __restrict__ Jp,
+                                  double* __restrict__ err, double* __restrict__ H) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const double* T = poses + ((size_t)m * L + joint) * 16;
+  const double* J6 = Jp ? Jp + ((size_t)m * L + joint) * 6 * D : nullptr;
+  const int rows = mode == 2 ? 6 : 3;
+  double* e = err + (size_t)m * rows;
+  double* Hm = H ? H + (size_t)m * rows * D : nullptr;
+  double Rm[9], t[3], Rd[9], td[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      Rm[i * 3 + j] = T[i * 4 + j];
+      Rd[i * 3 + j] = des[i * 4 + j];
+    }
+    t[i] = T[i * 4 + 3];
+    td[i] = des[i * 4 + 3];
+  }
+  if (mode == 0) {
+    for (int i = 0; i < 3; i++) e[i] = t[i] - td[i];
+    if (Hm)  // Pose3::translation(H) = [0 R]
+      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < D; k++) {
+          double a = 0;
+          for (int c = 0; c < 3; c++) a += Rm[i * 3 + c] * J6[(3 + c) * D + k];
+          Hm[i * D + k] = a;
+        }
+    return;
+  }
+  double Rrel[9], trel[3];  // between(des, pose)
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      double a = 0;
+      for (int c = 0; c < 3; c++) a += Rd[c * 3 + i] * Rm[c * 3 + j];
+      Rrel[i * 3 + j] = a;
+    }
+    trel[i] = Rd[i] * (t[0] - td[0]) + Rd[3 + i] * (t[1] - td[1]) + Rd[6 + i] * (t[2] - td[2]);
+  }
+  if (mode == 1) {
+    double w[3], Her[9];
+    rot3_logmap(Rrel, w);
+    for (int i = 0; i < 3; i++) e[i] = w[i];
+    if (Hm) {
+      rot3_logmap_derivative(w, Her);  // Pose3::rotation(H) = [I 0]
+      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < D; k++) {
+          double a = 0;
+          for (int c = 0; c < 3; c++) a += Her[i * 3 + c] * J6[c * D + k];
+          Hm[i * D + k] = a;
+        }
+    }
+    return;
+  }
+  double xi[6];
+  pose3_logmap(Rrel, trel, xi);
+  for (int i = 0; i < 6; i++) e[i] = xi[i];
+  if (Hm) {
+    double Hep[36];
+    pose3_logmap_derivative(Rrel, trel, Hep);
+    for (int i = 0; i < 6; i++)
+      for (int k = 0; k < D; k++) {
+        double a = 0;
+        for (int c = 0; c < 6; c++) a += Hep[i * 6 + c] * J6[c * D + k];
+        Hm[i * D + k] = a;
+      }
+  }
+}
+
+// SelfCollision::evaluateError obstacle/SelfCollision.h:66-128 on the sphere centres / Jacobians
+// k_sphere_centers produced: c [M][S][3], Jc [M][S][3][D]; data [n][4]; radius [S] (caller's order)
+__global__ void k_self_collision(int n, int S, int D, int M, const double* __restrict__ data,
+                                 const double* __restrict__ radius, const double* __restrict__ c,
+                                 const double* __restrict__ Jc, double* __restrict__ err, double* __restrict__ H) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= M * n) return;
+  const int m = t / n, i = t - m * n;
+  const int a = (int)data[i * 4 + 0], b = (int)data[i * 4 + 1];
+  const double eps = radius[a] + radius[b] + data[i * 4 + 2];
+  const double* ca = c + ((size_t)m * S + a) * 3;
+  const double* cb = c + ((size_t)m * S + b) * 3;
+  const double dx = ca[0] - cb[0], dy = ca[1] - cb[1], dz = ca[2] - cb[2];
+  const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  const bool active = !(dist > eps);
+  err[t] = active ? eps - dist : 0.0;
+  if (!H) return;
+  double* Hr = H + (size_t)t * D;
+  const double nn[3] = {dx / dist, dy / dist, dz / dist};
+  const double* Ja = Jc + ((size_t)m * S + a) * 3 * D;
+  const double* Jb = Jc + ((size_t)m * S + b) * 3 * D;
+  for (int k = 0; k < D; k++) {
+    double v = 0;
+    for (int q = 0; q < 3; q++) v += -nn[q] * Ja[q * D + k] + nn[q] * Jb[q * D + k];
+    Hr[k] = active ? v : 0.0;
+  }
+}
+
 // JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
 __global__ void k_joint_limit(int D, const double* __restrict__ down, const double* __restrict__ up,
                               const double* __restrict__ th, int M, const double* __restrict__ x,
@@ -539,6 +749,20 @@ int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N,
 #undef G2_IT
     default: set_error("dof must be 1..10"); return GPMP2MI_ERR_UNSUPPORTED;
   }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_workspace_prior(int mode, int joint, int L, int D, int M, const double* des, const double* poses,
+                           const double* Jp, double* err, double* H, hipStream_t st) {
+  k_workspace_prior<<<G2_GRID(M)>>>(mode, joint, L, D, M, des, poses, Jp, err, H);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_self_collision(int n, int S, int D, int M, const double* data, const double* radius, const double* c,
+                          const double* Jc, double* err, double* H, hipStream_t st) {
+  k_self_collision<<<G2_GRID(M * n)>>>(n, S, D, M, data, radius, c, Jc, err, H);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

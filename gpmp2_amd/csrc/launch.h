@@ -30,6 +30,10 @@ int launch_gp_prior_lie(int D, double dt, int M, const double* c1, const double*
                         hipStream_t st);
 int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N, int start, int Mo,
                             const double* traj, double* out, hipStream_t st);
+int launch_workspace_prior(int mode, int joint, int L, int D, int M, const double* des, const double* poses,
+                           const double* Jp, double* err, double* H, hipStream_t st);
+int launch_self_collision(int n, int S, int D, int M, const double* data, const double* radius, const double* c,
+                          const double* Jc, double* err, double* H, hipStream_t st);
 int launch_gp_interp_lie(int D, const GpCoef& gc, int M, const double* c1, const double* v1, const double* c2,
                          const double* v2, double* conf, double* vel, hipStream_t st);
 int launch_joint_limit(int D, const double* down, const double* up, const double* th, int M,

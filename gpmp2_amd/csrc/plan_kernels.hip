@@ -24,6 +24,11 @@
 namespace g2 {
 
 // =============================================================================== linearize
+#ifdef G2_STAMPS
+#define G2_LSTAMP(k) do { if (chunk == 1 && threadIdx.x == 0) pb.stamps[(size_t)b * 64 + 48 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G2_LSTAMP(k) do {} while (0)
+#endif
 template <int KIND, int AD, int SDIM>
 __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
                                                    const PlanParams* __restrict__ pp,
@@ -37,10 +42,19 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   if (active && !active[b]) return;
   double* __restrict__ rec = rec_of(pb, pb.which[b], bufsel);
   double* __restrict__ gpu = gpu_of(pb, pb.which[b], bufsel);
+  G2_LSTAMP(0);
+  // robot model -> LDS: the global loads are issued first and committed after the state loads and
+  // the GP interpolation below, so their latency overlaps
   __shared__ RobotDev R;
-  stage_robot(&R, Rg);
-  const int p = chunk * 64 + threadIdx.x;
-  if (p >= P.P) return;
+  constexpr int RN = sizeof(RobotDev) / 4, RPT = (RN + 63) / 64;
+  int rtmp[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+    const int idx = threadIdx.x + 64 * u;
+    rtmp[u] = idx < RN ? reinterpret_cast<const int*>(Rg)[idx] : 0;
+  }
+  const int p_raw = chunk * 64 + threadIdx.x;
+  const int p = min(p_raw, P.P - 1);  // tail lanes shadow the last point until the barrier below
   const int N = P.N, I = P.I;
   int i = 0, j = I;
   if (p > 0) {
@@ -75,6 +89,14 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     }
   }
 
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+    const int idx = threadIdx.x + 64 * u;
+    if (idx < RN) reinterpret_cast<int*>(&R)[idx] = rtmp[u];
+  }
+  __syncthreads();
+  if (p_raw >= P.P) return;
+  G2_LSTAMP(2);
   double G[NG], gv[D], e = 0.0;
 #pragma unroll
   for (int k = 0; k < NG; k++) G[k] = 0.0;
@@ -84,6 +106,20 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   if (!(P.obs_skip_first && p == 0)) {
     const double eps = P.eps;
     double hx, hy, hz, r;
+    auto accumulate = [&](const double (&Jc)[D][3], auto nc) {
+      constexpr int NC = decltype(nc)::value;  // columns >= NC of this sphere's Jacobian are zero
+      double Jr[NC];
+#pragma unroll
+      for (int k = 0; k < NC; k++)
+        Jr[k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
+      e += r * r;
+#pragma unroll
+      for (int k = 0; k < NC; k++) {
+        gv[k] += Jr[k] * r;
+#pragma unroll
+        for (int k2 = k; k2 < NC; k2++) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
+      }
+    };
     K::visit_spheres(
         R, q,
         [&](int s, const double (&pt)[3]) {
@@ -92,21 +128,9 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
           // and the sphere's Jacobian is never formed
           return !(hx == 0.0 && hy == 0.0 && hz == 0.0 && r == 0.0);
         },
-        [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) {
-          constexpr int NC = decltype(nc)::value;  // columns >= NC of this sphere's Jacobian are zero
-          double Jr[NC];
-#pragma unroll
-          for (int k = 0; k < NC; k++)
-            Jr[k] = hx * Jc[k][0] + hy * Jc[k][1] + (SDIM == 3 ? hz * Jc[k][2] : 0.0);
-          e += r * r;
-#pragma unroll
-          for (int k = 0; k < NC; k++) {
-            gv[k] += Jr[k] * r;
-#pragma unroll
-            for (int k2 = k; k2 < NC; k2++) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
-          }
-        });
+        [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) { accumulate(Jc, nc); });
   }
+  G2_LSTAMP(5);
   const double w = P.obs_w;
   double* rb = rec + (size_t)b * P.REC * P.Ppad + p;
 #pragma unroll
@@ -123,6 +147,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     }
   }
 
+  G2_LSTAMP(6);
   // GP prior of the interval ending at state i.  Vector spaces: GaussianProcessPriorLinear
   // (gp/GaussianProcessPriorLinear.h:57-83) r = Phi z_{i-1} - z_i.  Pose2 robots:
   // GaussianProcessPriorLie<Pose2Vector> (gp/GaussianProcessPriorLie.h:61-86)
@@ -181,6 +206,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     }
     gb[(size_t)n * P.Npad] = en;
   }
+  G2_LSTAMP(7);
 }
 
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
@@ -188,7 +214,9 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
                      hipStream_t st) {
   // One lane per evaluation point.  (A 4-lanes-per-point variant that splits the body spheres was
   // measured and rejected: the per-lane cost is dominated by the kinematic chain, which every lane
-  // would repeat -- 44 us vs 26 us at B = 64, no gain even at B = 1)
+  // would repeat -- 44 us vs 26 us at B = 64, no gain even at B = 1.  A two-sweep variant that kept
+  // 8 SDF lookups in flight was no faster either: the wave is fp64-issue bound, not latency bound;
+  // DESIGN.md section 4.)
   const dim3 grid(hp.B * (hp.Ppad / 64)), block(64);
   if (sdf.dim == 3) {
     G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));

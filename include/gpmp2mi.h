@@ -329,6 +329,28 @@ int gpmp2mi_interpolate_traj_dev(int dof, int lie, double delta_t, int inter_ste
                                  int total_step, int start_index, int end_index,
                                  const double* traj, double* out, void* stream);
 
+/* GaussianPriorWorkspace{Position,Orientation,Pose}::evaluateError
+ * kinematics/GaussianPriorWorkspacePosition.h:52-67, ...Orientation.h:52-69, ...Pose.h:53-70:
+ * prior on the world pose of link `joint`.  des_pose: row-major 4x4 (position mode uses its
+ * translation, orientation mode its rotation).  -> err [M][3|3|6] (pose: [omega; u] of
+ * Pose3::Logmap(des^-1 * pose)), H [M][rows][D] (may be NULL).  Rot3 / Pose3 log maps follow
+ * GTSAM 4.0 (upstream; pinned by the reference's known answers). */
+#define GPMP2MI_WORKSPACE_POSITION 0
+#define GPMP2MI_WORKSPACE_ORIENTATION 1
+#define GPMP2MI_WORKSPACE_POSE 2
+int gpmp2mi_workspace_prior_factor(const gpmp2mi_robot* r, int mode, int joint,
+                                   const double des_pose[16], int M, const double* conf,
+                                   double* err, double* H);
+/* GoalFactorArm::evaluateError kinematics/GoalFactorArm.h:58-77: end-effector position minus
+ * dest_point (= the position prior on the last link).  -> err [M][3], H [M][3][D] */
+int gpmp2mi_goal_factor_arm(const gpmp2mi_robot* r, const double dest_point[3], int M,
+                            const double* conf, double* err, double* H);
+/* SelfCollision::evaluateError obstacle/SelfCollision.h:66-128.  data [n_pairs][4] = (sphere A id,
+ * sphere B id, epsilon, sigma) with ids in the order of the robot description; hinge on
+ * radius_A + radius_B + epsilon - |c_A - c_B|.  -> err [M][n_pairs], H [M][n_pairs][D] */
+int gpmp2mi_self_collision_factor(const gpmp2mi_robot* r, int n_pairs, const double* data, int M,
+                                  const double* conf, double* err, double* H);
+
 /* JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
  * kinematics/JointLimitFactorVector.h:62-79, kinematics/VelocityLimitFactorVector.h:62-79.
  * x [M][D] -> err [M][D], Hdiag [M][D] (the diagonal of the Jacobian). */

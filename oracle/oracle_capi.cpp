@@ -155,6 +155,25 @@ int orc_sphere_centers(const void* r, int M, const double* conf, double* c, doub
   return 0;
 }
 
+int orc_workspace_prior_factor(const void* r, int mode, int joint, const double* des, int M, const double* conf,
+                               double* err, double* H) {
+  const Robot& R = *(const Robot*)r;
+  const int rows = mode == WS_POSE ? 6 : 3, D = R.dof;
+  for (int m = 0; m < M; m++)
+    workspace_prior_factor(R, mode, joint, des, conf + (size_t)m * D, err + (size_t)m * rows,
+                           H ? H + (size_t)m * rows * D : nullptr);
+  return 0;
+}
+
+int orc_self_collision_factor(const void* r, int n_pairs, const double* data, int M, const double* conf, double* err,
+                              double* H) {
+  const Robot& R = *(const Robot*)r;
+  for (int m = 0; m < M; m++)
+    self_collision_factor(R, n_pairs, data, conf + (size_t)m * R.dof, err + (size_t)m * n_pairs,
+                          H ? H + (size_t)m * n_pairs * R.dof : nullptr);
+  return 0;
+}
+
 int orc_obstacle_factor(const void* r, const void* s, double eps, int M, const double* conf,
                         double* err, double* H1) {
   const Robot& R = *(const Robot*)r;

@@ -224,6 +224,220 @@ void pose2_logmap_derivative(const Pose2& p, double J[9]) {
   }
 }
 
+// =============================================================================== SO(3) / SE(3) logs
+static void skew(const double w[3], double W[9]) {
+  W[0] = 0; W[1] = -w[2]; W[2] = w[1];
+  W[3] = w[2]; W[4] = 0; W[5] = -w[0];
+  W[6] = -w[1]; W[7] = w[0]; W[8] = 0;
+}
+static void m3mul(const double* A, const double* B, double* C) {
+  double T[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+  std::memcpy(C, T, sizeof(T));
+}
+// gtsam SO3::Logmap (4.0): trace based, special branch near pi, series near 0
+void rot3_logmap(const double R[9], double w[3]) {
+  const double R11 = R[0], R12 = R[1], R13 = R[2], R21 = R[3], R22 = R[4], R23 = R[5], R31 = R[6], R32 = R[7], R33 = R[8];
+  const double tr = R11 + R22 + R33;
+  if (std::fabs(tr + 1.0) < 1e-10) {
+    if (std::fabs(R33 + 1.0) > 1e-10) {
+      const double k = M_PI / std::sqrt(2.0 + 2.0 * R33);
+      w[0] = k * R13; w[1] = k * R23; w[2] = k * (1.0 + R33);
+    } else if (std::fabs(R22 + 1.0) > 1e-10) {
+      const double k = M_PI / std::sqrt(2.0 + 2.0 * R22);
+      w[0] = k * R12; w[1] = k * (1.0 + R22); w[2] = k * R32;
+    } else {
+      const double k = M_PI / std::sqrt(2.0 + 2.0 * R11);
+      w[0] = k * (1.0 + R11); w[1] = k * R21; w[2] = k * R31;
+    }
+  } else {
+    double magnitude;
+    const double tr_3 = tr - 3.0;
+    if (tr_3 < -1e-7) {
+      const double theta = std::acos((tr - 1.0) / 2.0);
+      magnitude = theta / (2.0 * std::sin(theta));
+    } else {
+      magnitude = 0.5 - tr_3 * tr_3 / 12.0;
+    }
+    w[0] = magnitude * (R32 - R23);
+    w[1] = magnitude * (R13 - R31);
+    w[2] = magnitude * (R21 - R12);
+  }
+}
+// gtsam SO3::LogmapDerivative
+void rot3_logmap_derivative(const double w[3], double H[9]) {
+  const double theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  for (int i = 0; i < 9; i++) H[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  if (theta2 <= std::numeric_limits<double>::epsilon()) return;
+  const double theta = std::sqrt(theta2);
+  double W[9], WW[9];
+  skew(w, W);
+  m3mul(W, W, WW);
+  const double k = 1.0 / (theta * theta) - (1.0 + std::cos(theta)) / (2.0 * theta * std::sin(theta));
+  for (int i = 0; i < 9; i++) H[i] += 0.5 * W[i] + k * WW[i];
+}
+// gtsam Pose3::Logmap: xi = [omega; u]
+void pose3_logmap(const double R[9], const double T[3], double xi[6]) {
+  double w[3];
+  rot3_logmap(R, w);
+  const double t = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (t < 1e-10) {
+    xi[3] = T[0]; xi[4] = T[1]; xi[5] = T[2];
+    return;
+  }
+  const double wn[3] = {w[0] / t, w[1] / t, w[2] / t};
+  double W[9];
+  skew(wn, W);
+  const double Tan = std::tan(0.5 * t);
+  double WT[3], WWT[3];
+  for (int i = 0; i < 3; i++) WT[i] = W[i * 3] * T[0] + W[i * 3 + 1] * T[1] + W[i * 3 + 2] * T[2];
+  for (int i = 0; i < 3; i++) WWT[i] = W[i * 3] * WT[0] + W[i * 3 + 1] * WT[1] + W[i * 3 + 2] * WT[2];
+  for (int i = 0; i < 3; i++) xi[3 + i] = T[i] - (0.5 * t) * WT[i] + (1.0 - t / (2.0 * Tan)) * WWT[i];
+}
+// gtsam Pose3::computeQforExpmapDerivative (Barfoot eq. 102 with the sign convention of gtsam)
+static void pose3_Q(const double xi[6], double Q[9]) {
+  const double* w = xi;
+  const double* v = xi + 3;
+  double V[9], W[9];
+  skew(v, V);
+  skew(w, W);
+  double WV[9], VW[9], WVW[9], WWV[9], VWW[9], WVWW[9], WWVW[9], WW[9];
+  m3mul(W, V, WV);
+  m3mul(V, W, VW);
+  m3mul(WV, W, WVW);
+  m3mul(W, W, WW);
+  m3mul(WW, V, WWV);
+  m3mul(VW, W, VWW);
+  m3mul(WVW, W, WVWW);
+  m3mul(W, WVW, WWVW);
+  const double phi = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  double c1, c2, c3;
+  if (std::fabs(phi) > 1e-5) {
+    const double s = std::sin(phi), c = std::cos(phi);
+    const double phi2 = phi * phi, phi3 = phi2 * phi, phi4 = phi3 * phi, phi5 = phi4 * phi;
+    c1 = (phi - s) / phi3;
+    c2 = (1.0 - phi2 / 2.0 - c) / phi4;
+    c3 = -0.5 * ((1.0 - phi2 / 2.0 - c) / phi4 - 3.0 * (phi - s - phi3 / 6.0) / phi5);
+  } else {
+    c1 = 1.0 / 6.0;
+    c2 = 1.0 / 24.0;
+    c3 = -0.5 * (1.0 / 24.0 + 3.0 / 120.0);
+  }
+  for (int i = 0; i < 9; i++)
+    Q[i] = -0.5 * V[i] + c1 * (WV[i] + VW[i] - WVW[i]) + c2 * (WWV[i] + VWW[i] - 3.0 * WVW[i]) + c3 * (WVWW[i] + WWVW[i]);
+}
+// gtsam Pose3::LogmapDerivative: [Jw 0; -Jw Q Jw, Jw]
+void pose3_logmap_derivative(const double R[9], const double T[3], double H[36]) {
+  double xi[6], Jw[9], Q[9], Q2[9];
+  pose3_logmap(R, T, xi);
+  rot3_logmap_derivative(xi, Jw);
+  pose3_Q(xi, Q);
+  m3mul(Jw, Q, Q2);
+  m3mul(Q2, Jw, Q2);
+  for (int i = 0; i < 36; i++) H[i] = 0.0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      H[i * 6 + j] = Jw[i * 3 + j];
+      H[(3 + i) * 6 + 3 + j] = Jw[i * 3 + j];
+      H[(3 + i) * 6 + j] = -Q2[i * 3 + j];
+    }
+}
+
+void workspace_prior_factor(const Robot& R, int mode, int joint, const double des[16], const double* conf,
+                            double* err, double* H) {
+  const int D = R.dof, L = R.nr_links();
+  std::vector<double> poses(16 * L), Jp((size_t)L * 6 * D);
+  forward_kinematics(R, conf, poses.data(), Jp.data());
+  const double* T = &poses[16 * joint];
+  const double* J6 = &Jp[(size_t)joint * 6 * D];
+  double Rm[9], t[3], Rd[9], td[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      Rm[i * 3 + j] = T[i * 4 + j];
+      Rd[i * 3 + j] = des[i * 4 + j];
+    }
+    t[i] = T[i * 4 + 3];
+    td[i] = des[i * 4 + 3];
+  }
+  if (mode == WS_POSITION) {
+    // Pose3::translation(H) = [0 R]
+    for (int i = 0; i < 3; i++) err[i] = t[i] - td[i];
+    if (H)
+      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < D; k++) {
+          double a = 0;
+          for (int m = 0; m < 3; m++) a += Rm[i * 3 + m] * J6[(3 + m) * D + k];
+          H[i * D + k] = a;
+        }
+    return;
+  }
+  // between(des, pose): R_rel = Rd^T R, t_rel = Rd^T (t - td)
+  double Rrel[9], trel[3];
+  for (int i = 0; i < 3; i++) {
+    for (int j = 0; j < 3; j++) {
+      double a = 0;
+      for (int m = 0; m < 3; m++) a += Rd[m * 3 + i] * Rm[m * 3 + j];
+      Rrel[i * 3 + j] = a;
+    }
+    trel[i] = Rd[0 * 3 + i] * (t[0] - td[0]) + Rd[1 * 3 + i] * (t[1] - td[1]) + Rd[2 * 3 + i] * (t[2] - td[2]);
+  }
+  if (mode == WS_ORIENTATION) {
+    rot3_logmap(Rrel, err);
+    if (H) {
+      double Her[9];
+      rot3_logmap_derivative(err, Her);  // Pose3::rotation(H) = [I 0]
+      for (int i = 0; i < 3; i++)
+        for (int k = 0; k < D; k++) {
+          double a = 0;
+          for (int m = 0; m < 3; m++) a += Her[i * 3 + m] * J6[m * D + k];
+          H[i * D + k] = a;
+        }
+    }
+    return;
+  }
+  pose3_logmap(Rrel, trel, err);
+  if (H) {
+    double Hep[36];
+    pose3_logmap_derivative(Rrel, trel, Hep);
+    for (int i = 0; i < 6; i++)
+      for (int k = 0; k < D; k++) {
+        double a = 0;
+        for (int m = 0; m < 6; m++) a += Hep[i * 6 + m] * J6[m * D + k];
+        H[i * D + k] = a;
+      }
+  }
+}
+
+void self_collision_factor(const Robot& R, int n_pairs, const double* data, const double* conf, double* err,
+                           double* H) {
+  const int D = R.dof, S = R.nr_spheres();
+  std::vector<double> c(3 * S), J(H ? (size_t)S * 3 * D : 0);
+  sphere_centers(R, conf, c.data(), H ? J.data() : nullptr);
+  for (int i = 0; i < n_pairs; i++) {
+    const int a = (int)data[i * 4 + 0], b = (int)data[i * 4 + 1];
+    const double eps = R.sph_r[a] + R.sph_r[b] + data[i * 4 + 2];
+    const double dx = c[3 * a] - c[3 * b], dy = c[3 * a + 1] - c[3 * b + 1], dz = c[3 * a + 2] - c[3 * b + 2];
+    const double dist = std::sqrt(dx * dx + dy * dy + dz * dz);  // gtsam::distance3: H_A = d^T/|d|, H_B = -H_A
+    if (H)
+      for (int k = 0; k < D; k++) H[(size_t)i * D + k] = 0.0;
+    if (dist > eps) {
+      err[i] = 0.0;
+      continue;
+    }
+    err[i] = eps - dist;
+    if (H) {
+      const double n[3] = {dx / dist, dy / dist, dz / dist};
+      for (int k = 0; k < D; k++) {
+        double v = 0;
+        for (int m = 0; m < 3; m++) v += -n[m] * J[((size_t)a * 3 + m) * D + k] + n[m] * J[((size_t)b * 3 + m) * D + k];
+        H[(size_t)i * D + k] = v;
+      }
+    }
+  }
+}
+
 // =============================================================================== SDF construction
 // matlab/+gpmp2/signedDistanceField3D.m:16-34 (bwdist) / gpmp2_python/utils/signedDistanceField3D.py:22-42
 // (scipy.ndimage.distance_transform_edt): exact Euclidean distance to the nearest cell of the

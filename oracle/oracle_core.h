@@ -124,6 +124,22 @@ void gp_prior_factor(int dof, bool lie, double delta_t, const double* c1, const 
                      const double* c2, const double* v2, double* err, Mat* H1, Mat* H2, Mat* H3,
                      Mat* H4);
 
+// ---------------------------------------------------------------- workspace / self-collision factors
+// Rot3 / Pose3 log maps with GTSAM 4.0 semantics (upstream, restated; pinned through the known answers of
+// kinematics/tests/testGaussianPriorWorkspace{Pose,Orientation}.cpp)
+void rot3_logmap(const double R[9], double w[3]);
+void rot3_logmap_derivative(const double w[3], double H[9]);
+void pose3_logmap(const double R[9], const double t[3], double xi[6]);
+void pose3_logmap_derivative(const double R[9], const double t[3], double H[36]);
+enum WorkspaceMode { WS_POSITION = 0, WS_ORIENTATION = 1, WS_POSE = 2 };
+// GaussianPriorWorkspace{Position,Orientation,Pose}::evaluateError (kinematics/GaussianPriorWorkspacePose.h:53-70
+// and siblings); des = row-major 4x4; err [3|3|6]; H [rows][dof] or null
+void workspace_prior_factor(const Robot& R, int mode, int joint, const double des[16], const double* conf,
+                            double* err, double* H);
+// SelfCollision::evaluateError obstacle/SelfCollision.h:66-128; data [n][4] = (sphere A, sphere B, eps, sigma)
+void self_collision_factor(const Robot& R, int n_pairs, const double* data, const double* conf, double* err,
+                           double* H /*[n][dof] or null*/);
+
 // ---------------------------------------------------------------- settings / graph / optimizer
 struct Settings {
   int dof = 0, total_step = 10;

@@ -15,6 +15,8 @@ for b in (0, 33):
     t = np.array(list(out), dtype=np.float64)
     k = int((t > 0).sum())
     d = np.diff(t[:k])
+    tl = np.array(list(out)[48:56], dtype=np.float64)
+    print('   linearize wave (b, chunk 1): stage_robot/state+interp/sweep1/lookups/sweep2/stores/gp cycles', [int(x) for x in np.diff(tl)])
     ta = np.array(list(out)[32:40], dtype=np.float64)
     print('   assemble wave (b, i=1): stage/build/misc/elim/store cycles', [int(x) for x in np.diff(ta[:6])])
     print(path.split('/')[-1], 'traj', b, 'phases(cycles/100MHz ticks?):', [int(x) for x in d], 'total', int(t[k-1]-t[0]))

@@ -163,6 +163,25 @@ class Oracle:
                                       int(start_index), end_index, dptr(t), dptr(out))
         return out
 
+    def workspace_prior_factor(self, robot, mode, joint, des_pose, conf, jac=True):
+        """mode 0 position / 1 orientation / 2 pose; des_pose 4x4 -> err [M][3|3|6], H [M][rows][D]"""
+        q = f64(conf).reshape(-1, robot.dof)
+        M, rows = q.shape[0], 6 if mode == 2 else 3
+        des = f64(des_pose).reshape(4, 4)
+        err, H = np.zeros((M, rows)), (np.zeros((M, rows, robot.dof)) if jac else None)
+        self.lib.orc_workspace_prior_factor(robot.ptr, int(mode), int(joint), dptr(des), M, dptr(q), dptr(err),
+                                                    dptr(H))
+        return err, H
+
+    def self_collision_factor(self, robot, data, conf, jac=True):
+        """data [n][4] = (sphere A, sphere B, epsilon, sigma) -> err [M][n], H [M][n][D]"""
+        q = f64(conf).reshape(-1, robot.dof)
+        d = f64(data).reshape(-1, 4)
+        M, n = q.shape[0], d.shape[0]
+        err, H = np.zeros((M, n)), (np.zeros((M, n, robot.dof)) if jac else None)
+        self.lib.orc_self_collision_factor(robot.ptr, n, dptr(d), M, dptr(q), dptr(err), dptr(H))
+        return err, H
+
     def joint_limit_factor(self, down, up, thresh, x):
         down, up, thresh = f64(down).reshape(-1), f64(up).reshape(-1), f64(thresh).reshape(-1)
         D = down.size

@@ -273,3 +273,71 @@ def test_sdf_read_vol(engine, tmp_path):
     (tmp_path / "short.vol.data").write_text("1.0 2.0")
     with pytest.raises(Exception):
         engine.sdf_read_vol(tmp_path / "short")
+
+
+# ------------------------------------------------------------------ SelfCollision / goal / workspace priors
+def _gold_arm(d):
+    arm = g.Arm(d["arm"]["dof"], vec(d["arm"]["a"]), vec(d["arm"]["alpha"]), vec(d["arm"]["d"]), g.pose3(t=d["arm"]["base_xyz"]))
+    return g.ArmModel(arm, [g.BodySphere(int(s[0]), s[1], (s[2], s[3], s[4])) for s in d["spheres"]])
+
+
+def test_self_collision_factor_gpu(engine, oracle, golden):
+    d = golden["self_collision"]                               # testSelfCollision.cpp:21-50
+    model = _gold_arm(d)
+    r, ro = engine.robot(model), oracle.robot(model)
+    err, H = engine.self_collision_factor(r, d["data"], vec(d["q"]))
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    rng = np.random.default_rng(4)
+    q = rng.uniform(-2, 2, size=(40, 3))
+    data = [[0, 1, 2.0, 0.1], [2, 3, 5.0, 0.1], [0, 3, 0.3, 0.2], [1, 3, 0.1, 0.2]]
+    a, b = engine.self_collision_factor(r, data, q), oracle.self_collision_factor(ro, data, q)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-11)
+    assert (b[0] == 0).any() and (b[0] > 0).any()             # both hinge branches exercised
+    # WAM sphere model: ids refer to the description's order although the engine sorts spheres by link
+    wam = g.generateArm("WAMArm")
+    rw, rwo = engine.robot(wam), oracle.robot(wam)
+    qw = rng.uniform(-1.5, 1.5, size=(25, 7))
+    dw = [[0, 15, 0.4, 0.1], [3, 12, 0.2, 0.1], [5, 9, 0.6, 0.1]]
+    a, b = engine.self_collision_factor(rw, dw, qw), oracle.self_collision_factor(rwo, dw, qw)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-12)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-11)
+    with pytest.raises(g.engine.Gpmp2miError):
+        engine.self_collision_factor(rw, [[0, 99, 0.1, 0.1]], qw)
+
+
+def test_goal_and_workspace_priors_gpu(engine, oracle, golden):
+    d = golden["goal_factor_arm"]                              # testGoalFactorArm.cpp:26-70
+    r = engine.robot(_gold_arm(d))
+    for c in d["cases"]:
+        err, _ = engine.goal_factor_arm(r, c["goal"], vec(c["q"]))
+        np.testing.assert_allclose(err[0], c["expected"], atol=d["tol"])
+    d = golden["workspace_pose"]                               # testGaussianPriorWorkspacePose.cpp:27-45
+    r = engine.robot(_gold_arm(d))
+    err, _ = engine.workspace_prior_factor(r, 2, d["joint"], np.eye(4), vec(d["q"]))
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    d = golden["workspace_orientation"]                        # ...Orientation.cpp:27-46
+    z = num(d["des_rzryrx"][2])
+    des = np.eye(4)
+    des[:2, :2] = [[math.cos(z), -math.sin(z)], [math.sin(z), math.cos(z)]]
+    err, _ = engine.workspace_prior_factor(r, 1, d["joint"], des, vec(d["q"]))
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    # batched parity on the WAM arm and on a mobile manipulator, all three modes, several links
+    rng = np.random.default_rng(23)
+    A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    A *= np.sign(np.linalg.det(A))
+    des = np.eye(4)
+    des[:3, :3] = A
+    des[:3, 3] = [0.3, -0.2, 0.5]
+    for model, joints in ((g.generateArm("WAMArm"), (0, 3, 6)), (g.generateMobileArm("SimpleTwoLinksArm"), (0, 2))):
+        r, ro = engine.robot(model), oracle.robot(model)
+        q = rng.uniform(-1.5, 1.5, size=(30, model.dof()))
+        q[0] = 0.0                                              # identity-ish poses: the small-angle branches
+        for mode in (0, 1, 2):
+            for joint in joints:
+                a = engine.workspace_prior_factor(r, mode, joint, des, q)
+                b = oracle.workspace_prior_factor(ro, mode, joint, des, q)
+                np.testing.assert_allclose(a[0], b[0], atol=1e-11)
+                np.testing.assert_allclose(a[1], b[1], atol=1e-10)
+    with pytest.raises(g.engine.Gpmp2miError):
+        engine.workspace_prior_factor(r, 2, 7, des, q)

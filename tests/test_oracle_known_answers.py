@@ -462,3 +462,76 @@ def test_sdf_from_occupancy_degenerate_maps(oracle):
     d = g.generate2Ddataset("OneObstacleDataset")
     np.testing.assert_array_equal(oracle.sdf_field_from_occupancy(d.map, d.cell_size),
                                   g.datasets.signedDistanceField2D(d.map, d.cell_size))
+
+
+# ------------------------------------------------------------------ SelfCollision / goal / workspace priors
+def _arm(d):
+    arm = g.Arm(d["arm"]["dof"], vec(d["arm"]["a"]), vec(d["arm"]["alpha"]), vec(d["arm"]["d"]), g.pose3(t=d["arm"]["base_xyz"]))
+    return g.ArmModel(arm, [g.BodySphere(int(s[0]), s[1], (s[2], s[3], s[4])) for s in d["spheres"]])
+
+
+def _pose(R=None, t=(0, 0, 0)):
+    T = np.eye(4)
+    if R is not None:
+        T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def _rz(a):
+    return np.array([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1]])
+
+
+def test_self_collision_factor(oracle, golden):
+    d = golden["self_collision"]                               # testSelfCollision.cpp:21-50
+    r = oracle.robot(_arm(d))
+    q = vec(d["q"])
+    err, H = oracle.self_collision_factor(r, d["data"], q)
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    Hn = numeric_jacobian(lambda x: oracle.self_collision_factor(r, d["data"], x, jac=False)[0][0], q, 1e-6)
+    np.testing.assert_allclose(H[0], Hn, atol=1e-6)
+    # far apart -> zero residual and zero Jacobian (strict '>' as ObstacleCost)
+    far = [[0, 3, 0.5, 0.1]]
+    err, H = oracle.self_collision_factor(r, far, np.zeros(3))
+    assert err[0, 0] == 0.0 and not H.any()
+
+
+def test_goal_factor_and_workspace_position(oracle, golden):
+    for key in ("goal_factor_arm", "workspace_position"):
+        d = golden[key]                                        # testGoalFactorArm.cpp:26-70, ...Position.cpp:27-75
+        r = oracle.robot(_arm(d))
+        joint = d.get("joint", d["arm"]["dof"] - 1)            # GoalFactorArm = position prior on the last link
+        for c in d["cases"]:
+            q, des = vec(c["q"]), _pose(t=c.get("goal", c.get("des")))
+            err, H = oracle.workspace_prior_factor(r, 0, joint, des, q)
+            np.testing.assert_allclose(err[0], c["expected"], atol=d["tol"])
+            Hn = numeric_jacobian(lambda x: oracle.workspace_prior_factor(r, 0, joint, des, x, jac=False)[0][0], q, 1e-6)
+            np.testing.assert_allclose(H[0], Hn, atol=1e-6)
+
+
+def test_workspace_orientation_and_pose(oracle, golden):
+    d = golden["workspace_orientation"]                        # ...Orientation.cpp:27-46
+    r = oracle.robot(_arm(d))
+    q = vec(d["q"])
+    des = _pose(R=_rz(num(d["des_rzryrx"][2])))                # Rot3::RzRyRx(0, 0, z) = Rz(z)
+    err, H = oracle.workspace_prior_factor(r, 1, d["joint"], des, q)
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    Hn = numeric_jacobian(lambda x: oracle.workspace_prior_factor(r, 1, d["joint"], des, x, jac=False)[0][0], q, 1e-6)
+    np.testing.assert_allclose(H[0], Hn, atol=1e-6)
+    d = golden["workspace_pose"]                               # ...Pose.cpp:27-45
+    r = oracle.robot(_arm(d))
+    err, H = oracle.workspace_prior_factor(r, 2, d["joint"], np.eye(4), q)
+    np.testing.assert_allclose(err[0], d["expected"], atol=d["tol"])
+    Hn = numeric_jacobian(lambda x: oracle.workspace_prior_factor(r, 2, d["joint"], np.eye(4), x, jac=False)[0][0], q, 1e-6)
+    np.testing.assert_allclose(H[0], Hn, atol=1e-6)
+    # numerical Jacobians on a 7-dof arm with a non-trivial target (pattern A of SURVEY section 4)
+    wam = oracle.robot(g.generateArm("WAMArm"))
+    rng = np.random.default_rng(17)
+    qq = rng.uniform(-1.5, 1.5, size=7)
+    A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    A *= np.sign(np.linalg.det(A))
+    des = _pose(R=A, t=[0.3, -0.2, 0.5])
+    for mode in (0, 1, 2):
+        err, H = oracle.workspace_prior_factor(wam, mode, 6, des, qq)
+        Hn = numeric_jacobian(lambda x: oracle.workspace_prior_factor(wam, mode, 6, des, x, jac=False)[0][0], qq, 1e-6)
+        np.testing.assert_allclose(H[0], Hn, atol=1e-5)
