@@ -5,9 +5,11 @@ include/gpmp2mi.h; this package is the reference-shaped façade over it (robots,
 BatchTrajOptimize*, factor evaluateError) used by tests and bench.py.
 """
 from .datasets import generate2Ddataset, generate3Ddataset, sdf3_zyx  # noqa: F401
-from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pose2MobileArm,  # noqa: F401
-                     Pose2MobileArmModel, Pose2MobileBase, Pose2MobileBaseModel, generateArm,
-                     generateMobileArm, generatePointRobot, pose3, rot_yaw)
+from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pose2Mobile2Arms,  # noqa: F401
+                     Pose2Mobile2ArmsModel, Pose2MobileArm, Pose2MobileArmModel, Pose2MobileBase,
+                     Pose2MobileBaseModel, Pose2MobileVetLin2Arms, Pose2MobileVetLin2ArmsModel,
+                     Pose2MobileVetLinArm, Pose2MobileVetLinArmModel, generateArm, generateMobileArm,
+                     generatePointRobot, pose3, rot_yaw)
 from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2MobileArm,  # noqa: F401
                       BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,

@@ -26,7 +26,9 @@ class RobotDesc(C.Structure):
                 ("a", c_double_p), ("alpha", c_double_p), ("d", c_double_p),
                 ("theta_bias", c_double_p), ("base_pose", C.c_double * 16),
                 ("nr_spheres", C.c_int), ("sphere_link", c_int_p),
-                ("sphere_radius", c_double_p), ("sphere_center", c_double_p)]
+                ("sphere_radius", c_double_p), ("sphere_center", c_double_p),
+                ("arm2_dof", C.c_int), ("base_pose2", C.c_double * 16), ("base_pose3", C.c_double * 16),
+                ("reverse_linact", C.c_int)]
 
 
 class Settings(C.Structure):
@@ -86,6 +88,12 @@ def make_robot_desc(model):
     d.sphere_link = iptr(fl["sphere_link"])
     d.sphere_radius = dptr(fl["sphere_radius"])
     d.sphere_center = dptr(fl["sphere_center"])
+    d.arm2_dof = int(fl.get("arm2_dof", 0))
+    eye = np.eye(4).reshape(16)
+    for i in range(16):
+        d.base_pose2[i] = float(fl.get("base_pose2", eye)[i])
+        d.base_pose3[i] = float(fl.get("base_pose3", eye)[i])
+    d.reverse_linact = int(fl.get("reverse_linact", 0))
     return d, fl
 
 

@@ -251,14 +251,19 @@ int gpmp2mi_device_count(void) {
 int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
   G2_CHECK(d && out, GPMP2MI_ERR_INVALID, "null argument");
   *out = nullptr;
-  G2_CHECK(d->kind >= 0 && d->kind <= 3, GPMP2MI_ERR_INVALID, "unknown robot kind");
+  G2_CHECK(d->kind >= 0 && d->kind <= GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, GPMP2MI_ERR_INVALID, "unknown robot kind");
   G2_CHECK(d->arm_dof >= 0 && d->arm_dof <= MAXJ, GPMP2MI_ERR_UNSUPPORTED, "arm dof > 8");
   G2_CHECK(d->nr_spheres >= 0 && d->nr_spheres <= MAXS, GPMP2MI_ERR_UNSUPPORTED, "too many body spheres");
-  const int base = (d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_BASE || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? 3 : 0;
-  const int dof = (d->kind == GPMP2MI_ROBOT_POINT) ? 2 : base + d->arm_dof;
+  const bool mobile = d->kind >= GPMP2MI_ROBOT_POSE2_MOBILE_BASE;
+  const bool lift = d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS;
+  const bool two = d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS;
+  const int base = mobile ? 3 : 0;
+  const int dof = (d->kind == GPMP2MI_ROBOT_POINT) ? 2 : base + (lift ? 1 : 0) + d->arm_dof;
   G2_CHECK(d->dof == dof, GPMP2MI_ERR_INVALID, "dof does not match robot kind / arm_dof");
-  if (d->kind == GPMP2MI_ROBOT_ARM || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM)
+  G2_CHECK(dof <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "total dof > 11");
+  if (d->kind == GPMP2MI_ROBOT_ARM || d->kind >= GPMP2MI_ROBOT_POSE2_MOBILE_ARM)
     G2_CHECK(d->arm_dof > 0 && d->a && d->alpha && d->d, GPMP2MI_ERR_INVALID, "missing DH parameters");
+  if (two) G2_CHECK(d->arm2_dof > 0 && d->arm2_dof < d->arm_dof, GPMP2MI_ERR_INVALID, "arm2_dof must split arm_dof into two arms");
   G2_TRY(ensure_device());
   auto r = std::make_unique<gpmp2mi_robot>();
   RobotDev& h = r->h;
@@ -266,9 +271,10 @@ int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
   h.kind = d->kind;
   h.dof = dof;
   h.arm_dof = d->arm_dof;
+  h.arm2_dof = two ? d->arm2_dof : 0;
+  h.reverse_linact = lift ? (d->reverse_linact != 0) : 0;
   h.base_dof = base;
-  h.nr_links = (d->kind == GPMP2MI_ROBOT_ARM) ? d->arm_dof
-               : (d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? d->arm_dof + 1 : 1;
+  h.nr_links = (d->kind == GPMP2MI_ROBOT_ARM) ? d->arm_dof : mobile ? 1 + (lift ? 1 : 0) + d->arm_dof : 1;
   h.nr_spheres = d->nr_spheres;
   for (int j = 0; j < d->arm_dof; j++) {
     h.a[j] = d->a[j];
@@ -278,7 +284,11 @@ int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
     h.bias[j] = d->theta_bias ? d->theta_bias[j] : 0.0;
   }
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 4; j++) h.base[i * 4 + j] = d->base_pose[i * 4 + j];
+    for (int j = 0; j < 4; j++) {
+      h.base[i * 4 + j] = d->base_pose[i * 4 + j];
+      h.base2[i * 4 + j] = (lift || two) ? d->base_pose2[i * 4 + j] : (i == j ? 1.0 : 0.0);
+      h.base3[i * 4 + j] = (lift && two) ? d->base_pose3[i * 4 + j] : (i == j ? 1.0 : 0.0);
+    }
   // sort spheres by link (stable) so the kinematic chain visits them in order
   std::vector<int> order(d->nr_spheres);
   std::iota(order.begin(), order.end(), 0);

@@ -46,7 +46,11 @@ void set_error(const std::string& msg);
 struct RobotDev {
   int kind, dof, arm_dof, nr_links, nr_spheres, base_dof, pad0, pad1;
   double ca[MAXJ], sa[MAXJ], a[MAXJ], d[MAXJ], bias[MAXJ];
-  double base[12];           // 3x4 row-major: ARM world_T_base, MOBILE_ARM base_T_arm
+  double base[12];           // 3x4 row-major: ARM world_T_base, MOBILE_ARM base_T_arm, 2ARMS base_T_arm1,
+                             // VETLIN_* base_T_torso
+  double base2[12];          // 2ARMS base_T_arm2; VETLIN_ARM torso_T_arm; VETLIN_2ARMS torso_T_arm1
+  double base3[12];          // VETLIN_2ARMS torso_T_arm2
+  int arm2_dof, reverse_linact;
   int sph_link[MAXS];        // ascending
   int sph_orig[MAXS];        // index in the caller's BodySphereVector
   int link_first[MAXJ + 2];  // first sorted sphere of each link, [nr_links] = nr_spheres

@@ -140,30 +140,120 @@ __device__ __forceinline__ void dh_advance(Frame& F, double theta, double a, dou
 
 // Generic visitor-style forward kinematics over a sphere model.
 //   KIND     : GPMP2MI_ROBOT_*
-//   AD       : number of DH joints (compile time; 0 for POINT / MOBILE_BASE)
-// For every sphere (sorted by link) calls  f(sorted_index, p[3], Jcol[DOF][3])  where
-// Jcol[k] = d p / d q_k (world frame; GTSAM right-perturbation for the Pose2 part) and only the
-// first `ncols` columns are non-zero.  Equivalent to RobotModel::sphereCenters
-// (kinematics/RobotModel-inl.h:12-40) composed with Arm::forwardKinematics' pose Jacobians
-// (kinematics/Arm.cpp:105-115): column k = z_k x (p - o_k)  (SURVEY.md appendix A.2).
-template <int KIND, int AD>
-struct Kin {
-  static constexpr int BASE = (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_BASE ||
-                               KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? 3 : 0;
-  static constexpr int DOF = (KIND == GPMP2MI_ROBOT_POINT) ? 2 : BASE + AD;
-  static constexpr int NLINKS = (KIND == GPMP2MI_ROBOT_ARM) ? AD
-                                : (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_ARM) ? AD + 1 : 1;
+//   AD       : number of DH joints of the (first) arm (compile time; 0 for POINT / MOBILE_BASE)
+//   AD2      : number of DH joints of the second arm (two-arm robots)
+// Robot = [vehicle base (Pose2)] [+ vertical lift torso] + arm 1 [+ arm 2]; configuration
+// [x, y, theta, (lift), q_arm1, q_arm2]; links in the reference's order: vehicle base, (torso),
+// arm-1 links, arm-2 links (kinematics/Pose2Mobile2Arms.cpp:32-108, Pose2MobileVetLinArm.cpp:31-108,
+// Pose2MobileVetLin2Arms.cpp:36-114).  Sphere Jacobians are world-frame columns
+// Jcol[k] = d p / d q_k (GTSAM right-perturbation for the Pose2 part): equivalent to
+// RobotModel::sphereCenters (kinematics/RobotModel-inl.h:12-40) composed with the pose Jacobians of
+// the FK models (kinematics/Arm.cpp:105-115): arm joint column = z_k x (p - o_k)  (SURVEY.md A.2).
+//
+// Column tag of a link: value = NC, columns >= NC are zero; columns [NB, first) are zero too (the
+// other arm's joints); columns [first, NC) belong to joints (first - NB) .. of the DH table.
+template <int NC, int FIRST>
+struct ColTag {
+  static constexpr int value = NC;
+  static constexpr int first = FIRST;
+};
 
-  // Joint axes / origins of one configuration: all a sphere Jacobian needs besides the sphere centre.
+template <int KIND, int AD, int AD2 = 0>
+struct Kin {
+  static constexpr bool MOBILE = KIND >= GPMP2MI_ROBOT_POSE2_MOBILE_BASE;
+  static constexpr int BASE = MOBILE ? 3 : 0;
+  static constexpr int LIFT = (KIND == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM ||
+                               KIND == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS) ? 1 : 0;
+  static constexpr int NB = BASE + LIFT;      // columns in front of the arm joints
+  static constexpr int NJ = AD + AD2;         // DH joints, arm 1 first
+  static constexpr int DOF = (KIND == GPMP2MI_ROBOT_POINT) ? 2 : NB + NJ;
+  static constexpr int NLINKS = (KIND == GPMP2MI_ROBOT_ARM) ? AD : MOBILE ? 1 + LIFT + NJ : 1;
+
+  // Joint axes / origins of one configuration: all a point Jacobian needs besides the point itself.
   struct Axes {
-    double zax[AD > 0 ? AD : 1][3], org[AD > 0 ? AD : 1][3];
+    double zax[NJ > 0 ? NJ : 1][3], org[NJ > 0 ? NJ : 1][3];
     double vt[3], bx[3], by[3];  // vehicle origin and heading columns (mobile robots)
+    double lift_sign;            // +-1: d torso / d lift = lift_sign * e_z
   };
 
-  // Walk the kinematic chain once: f(s, p, nc) for every body sphere in sorted order, with its world
-  // centre p and nc = integral_constant<number of leading non-zero Jacobian columns>; fills A on the way
-  // (A.zax[k], A.org[k] are valid for k < nc - BASE when f is called).
-  // sub / nsub: visit only the spheres s with s % nsub == sub (lane-split kernels); nsub a power of 2.
+  __device__ __forceinline__ static void compose(const Frame& P, const double* M3x4, Frame& N) {
+    Frame B;
+    frame_from_3x4(M3x4, B);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      N.c0[i] = P.c0[i] * B.c0[0] + P.c1[i] * B.c0[1] + P.c2[i] * B.c0[2];
+      N.c1[i] = P.c0[i] * B.c1[0] + P.c1[i] * B.c1[1] + P.c2[i] * B.c1[2];
+      N.c2[i] = P.c0[i] * B.c2[0] + P.c1[i] * B.c2[1] + P.c2[i] * B.c2[2];
+      N.t[i] = P.t[i] + P.c0[i] * B.t[0] + P.c1[i] * B.t[1] + P.c2[i] * B.t[2];
+    }
+  }
+
+  // Walk the kinematic tree once: f(link, F, tag) for every link in the reference's order with its
+  // world frame F and column tag; fills A on the way (A.zax[k], A.org[k] valid for the joints the
+  // tag covers when f is called).  POINT robots have no frame walk (see walk()).
+  template <class F>
+  __device__ __forceinline__ static void walk_links(const RobotDev& R, const double (&q)[DOF], Axes& A, F&& f) {
+    static_assert(KIND != GPMP2MI_ROBOT_POINT, "point robots have no link frames");
+    Frame Fr;
+    A.vt[0] = A.vt[1] = A.vt[2] = 0.0;
+    A.lift_sign = 1.0;
+    if constexpr (MOBILE) {
+      // computeBasePose3  kinematics/mobileBaseUtils.cpp:18-31
+      double sn, c;
+      sincos(q[2], &sn, &c);
+      Fr.c0[0] = c; Fr.c0[1] = sn; Fr.c0[2] = 0;
+      Fr.c1[0] = -sn; Fr.c1[1] = c; Fr.c1[2] = 0;
+      Fr.c2[0] = 0; Fr.c2[1] = 0; Fr.c2[2] = 1;
+      Fr.t[0] = q[0]; Fr.t[1] = q[1]; Fr.t[2] = 0;
+      A.vt[0] = q[0]; A.vt[1] = q[1];
+      A.bx[0] = c; A.bx[1] = sn; A.bx[2] = 0;
+      A.by[0] = -sn; A.by[1] = c; A.by[2] = 0;
+      f(0, Fr, ColTag<3, 3>{});  // link 0 = vehicle base
+      if constexpr (LIFT == 1) {
+        // liftBasePose3  kinematics/mobileBaseUtils.cpp:51-82: a world-z translation composed on
+        // the LEFT of veh * base_T_torso
+        Frame T;
+        compose(Fr, R.base, T);
+        A.lift_sign = R.reverse_linact ? -1.0 : 1.0;
+        T.t[2] += A.lift_sign * q[3];
+        Fr = T;
+        f(1, Fr, ColTag<NB, NB>{});  // link 1 = torso
+      }
+    } else {
+      frame_from_3x4(R.base, Fr);  // ARM: world_T_base
+    }
+    if constexpr (NJ > 0) {
+      const Frame parent = Fr;
+      // arm 1: computeBaseTransPose3 (mobileBaseUtils.cpp:34-48) / torso.compose(torso_T_arm)
+      if constexpr (MOBILE) compose(parent, LIFT ? R.base2 : R.base, Fr);
+      static_for<0, AD>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          A.zax[j][i] = Fr.c2[i];
+          A.org[j][i] = Fr.t[i];
+        }
+        dh_advance(Fr, q[NB + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
+        f((MOBILE ? 1 + LIFT : 0) + j, Fr, ColTag<NB + j + 1, NB>{});
+      });
+      if constexpr (AD2 > 0) {
+        compose(parent, LIFT ? R.base3 : R.base2, Fr);
+        static_for<0, AD2>([&](auto jc) {
+          constexpr int j = AD + decltype(jc)::value;
+#pragma unroll
+          for (int i = 0; i < 3; i++) {
+            A.zax[j][i] = Fr.c2[i];
+            A.org[j][i] = Fr.t[i];
+          }
+          dh_advance(Fr, q[NB + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
+          f(1 + LIFT + j, Fr, ColTag<NB + j + 1, NB + AD>{});
+        });
+      }
+    }
+  }
+
+  // f(s, p, tag) for every body sphere in sorted (= link) order, with its world centre p
+  // sub / nsub: visit only the spheres s with s % nsub == sub; nsub a power of 2.
   template <class F>
   __device__ __forceinline__ static void walk(const RobotDev& R, const double (&q)[DOF], Axes& A, F&& f,
                                               int sub = 0, int nsub = 1) {
@@ -173,117 +263,57 @@ struct Kin {
       for (int s = 0; s < R.nr_spheres; s++) {
         if ((s & smask) != sub) continue;
         const double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
-        f(s, p, std::integral_constant<int, 2>{});
+        f(s, p, ColTag<2, 0>{});
       }
     } else {
-      Frame Fr;
-      A.vt[0] = A.vt[1] = A.vt[2] = 0.0;
-      if constexpr (BASE == 3) {
-        // computeBasePose3  kinematics/mobileBaseUtils.cpp:18-31
-        double sn, c;
-        sincos(q[2], &sn, &c);
-        Fr.c0[0] = c; Fr.c0[1] = sn; Fr.c0[2] = 0;
-        Fr.c1[0] = -sn; Fr.c1[1] = c; Fr.c1[2] = 0;
-        Fr.c2[0] = 0; Fr.c2[1] = 0; Fr.c2[2] = 1;
-        Fr.t[0] = q[0]; Fr.t[1] = q[1]; Fr.t[2] = 0;
-        A.vt[0] = q[0]; A.vt[1] = q[1];
-        A.bx[0] = c; A.bx[1] = sn; A.bx[2] = 0;
-        A.by[0] = -sn; A.by[1] = c; A.by[2] = 0;
-        // link 0 = vehicle base
-        for (int s0 = R.link_first[0]; s0 < R.link_first[1]; s0++) {
-          if ((s0 & smask) != sub) continue;
+      walk_links(R, q, A, [&](int link, const Frame& Fr, auto tag) {
+        for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) {
+          if ((s & smask) != sub) continue;
           double p[3];
 #pragma unroll
           for (int i = 0; i < 3; i++)
-            p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s0] + Fr.c1[i] * R.sph_c[3 * s0 + 1] +
-                   Fr.c2[i] * R.sph_c[3 * s0 + 2];
-          f(s0, p, std::integral_constant<int, 3>{});
+            p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s] + Fr.c1[i] * R.sph_c[3 * s + 1] +
+                   Fr.c2[i] * R.sph_c[3 * s + 2];
+          f(s, p, tag);
         }
-        if constexpr (AD > 0) {
-          // arm base = veh * base_T_arm  (computeBaseTransPose3, mobileBaseUtils.cpp:34-48)
-          Frame B;
-          frame_from_3x4(R.base, B);
-          Frame N;
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            N.c0[i] = Fr.c0[i] * B.c0[0] + Fr.c1[i] * B.c0[1] + Fr.c2[i] * B.c0[2];
-            N.c1[i] = Fr.c0[i] * B.c1[0] + Fr.c1[i] * B.c1[1] + Fr.c2[i] * B.c1[2];
-            N.c2[i] = Fr.c0[i] * B.c2[0] + Fr.c1[i] * B.c2[1] + Fr.c2[i] * B.c2[2];
-            N.t[i] = Fr.t[i] + Fr.c0[i] * B.t[0] + Fr.c1[i] * B.t[1] + Fr.c2[i] * B.t[2];
-          }
-          Fr = N;
-        }
-      } else {
-        frame_from_3x4(R.base, Fr);
-      }
-      if constexpr (AD > 0) {
-        static_for<0, AD>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            A.zax[j][i] = Fr.c2[i];
-            A.org[j][i] = Fr.t[i];
-          }
-          dh_advance(Fr, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
-          constexpr int link = (BASE == 3) ? j + 1 : j;
-          for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) {
-            if ((s & smask) != sub) continue;
-            double p[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-              p[i] = Fr.t[i] + Fr.c0[i] * R.sph_c[3 * s] + Fr.c1[i] * R.sph_c[3 * s + 1] +
-                     Fr.c2[i] * R.sph_c[3 * s + 2];
-            f(s, p, std::integral_constant<int, BASE + j + 1>{});
-          }
-        });
-      }
+      });
     }
   }
 
-  // Jacobian columns of a sphere centre p from the axes of the walk: J[k] = d p / d q_k for k < NC
-  // (columns >= NC are not touched).  Column k of an arm joint = z_k x (p - o_k).
-  template <int NC>
-  __device__ __forceinline__ static void jacobian(const Axes& A, const double (&p)[3], std::integral_constant<int, NC>,
-                                                  double (&J)[DOF][3]) {
+  // Jacobian columns of a point p rigidly attached to a link with column tag `tag`:
+  // J[k] = d p / d q_k for k < tag.value (columns >= tag.value are not touched).
+  template <class Tag>
+  __device__ __forceinline__ static void jacobian(const Axes& A, const double (&p)[3], Tag, double (&J)[DOF][3]) {
+    constexpr int NC = Tag::value, FIRST = Tag::first;
     if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
       J[0][0] = 1.0; J[0][1] = 0.0; J[0][2] = 0.0;
       J[1][0] = 0.0; J[1][1] = 1.0; J[1][2] = 0.0;
     } else {
-      if constexpr (BASE == 3) {
+      if constexpr (MOBILE) {
 #pragma unroll
         for (int i = 0; i < 3; i++) { J[0][i] = A.bx[i]; J[1][i] = A.by[i]; }
         J[2][0] = -(p[1] - A.vt[1]);  // z x (p - t_veh)
         J[2][1] = (p[0] - A.vt[0]);
         J[2][2] = 0.0;
+        if constexpr (LIFT == 1 && NC > 3) { J[3][0] = 0.0; J[3][1] = 0.0; J[3][2] = A.lift_sign; }
       }
 #pragma unroll
-      for (int k = 0; k < NC - BASE; k++) {
-        const double rx = p[0] - A.org[k][0], ry = p[1] - A.org[k][1], rz = p[2] - A.org[k][2];
-        J[BASE + k][0] = A.zax[k][1] * rz - A.zax[k][2] * ry;
-        J[BASE + k][1] = A.zax[k][2] * rx - A.zax[k][0] * rz;
-        J[BASE + k][2] = A.zax[k][0] * ry - A.zax[k][1] * rx;
+      for (int k = NB; k < (FIRST < NC ? FIRST : NC); k++) J[k][0] = J[k][1] = J[k][2] = 0.0;  // the other arm
+#pragma unroll
+      for (int k = FIRST; k < NC; k++) {
+        const int jn = k - NB;
+        const double rx = p[0] - A.org[jn][0], ry = p[1] - A.org[jn][1], rz = p[2] - A.org[jn][2];
+        J[k][0] = A.zax[jn][1] * rz - A.zax[jn][2] * ry;
+        J[k][1] = A.zax[jn][2] * rx - A.zax[jn][0] * rz;
+        J[k][2] = A.zax[jn][0] * ry - A.zax[jn][1] * rx;
       }
-    }
-  }
-
-  // f(s, nc) for every sphere in sorted order with its compile-time column count (no kinematics)
-  template <class F>
-  __device__ __forceinline__ static void each_sphere(const RobotDev& R, F&& f) {
-    if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
-      for (int s = 0; s < R.nr_spheres; s++) f(s, std::integral_constant<int, 2>{});
-    } else {
-      static_for<0, NLINKS>([&](auto lc) {
-        constexpr int link = decltype(lc)::value;
-        constexpr int NC = (BASE == 3) ? 3 + link : link + 1;
-        for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) f(s, std::integral_constant<int, NC>{});
-      });
     }
   }
 
   // Visitor over the body spheres (sorted by link):
   //   pre(s, p) -> bool      : called with the sphere centre; return true if the Jacobian is wanted
-  //   post(s, p, J, nc)      : J[k] = d p / d q_k for k < nc (compile-time integral_constant nc),
-  //                            zero for k >= nc -- spheres on link j only depend on the first joints
+  //   post(s, p, J, nc)      : J[k] = d p / d q_k for k < nc.value (compile time),
+  //                            zero for k >= nc.value -- a sphere depends on the joints below its link only
   template <class Pre, class Post>
   __device__ __forceinline__ static void visit_spheres(const RobotDev& R, const double (&q)[DOF], Pre&& pre,
                                                        Post&& post, int sub = 0, int nsub = 1) {

@@ -4,15 +4,20 @@
 #pragma once
 #include "common.h"
 
-#define G2_CASE_(K, A, kind, ad, STMT)                 \
-  if (!done_ && (kind) == (K) && (ad) == (A)) {        \
-    constexpr int KIND_ = (K);                         \
-    constexpr int AD_ = (A);                           \
-    STMT;                                              \
-    done_ = true;                                      \
+#define G2_CASE2_(K, A, A2, kind, ad, ad2, STMT)                  \
+  if (!done_ && (kind) == (K) && (ad) == (A) && (ad2) == (A2)) {  \
+    constexpr int KIND_ = (K);                                    \
+    constexpr int AD_ = (A);                                      \
+    constexpr int AD2_ = (A2);                                    \
+    STMT;                                                         \
+    done_ = true;                                                 \
   }
+#define G2_CASE_(K, A, kind, ad, STMT) G2_CASE2_(K, A, 0, kind, ad, 0, STMT)
 
-#define G2_DISPATCH_ROBOT(kind, ad, STMT)                                             \
+// (kind, joints of arm 1, joints of arm 2) of a robot handle `h` (RobotDev)
+#define G2_DISPATCH_ROBOT_H(h, STMT) G2_DISPATCH_ROBOT2((h).kind, (h).arm_dof - (h).arm2_dof, (h).arm2_dof, STMT)
+#define G2_DISPATCH_ROBOT(kind, ad, STMT) G2_DISPATCH_ROBOT2(kind, ad, 0, STMT)
+#define G2_DISPATCH_ROBOT2(kind, ad, ad2, STMT)                                           \
   do {                                                                                \
     bool done_ = false;                                                               \
     G2_CASE_(GPMP2MI_ROBOT_ARM, 1, kind, ad, STMT)                                    \
@@ -26,6 +31,11 @@
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_BASE, 0, kind, ad, STMT)                      \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 2, kind, ad, STMT)                       \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 3, kind, ad, STMT)                       \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 1, 1, kind, ad, ad2, STMT)            \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 2, 2, kind, ad, ad2, STMT)            \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 2, 0, kind, ad, ad2, STMT)       \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 3, 0, kind, ad, ad2, STMT)       \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 2, 2, kind, ad, ad2, STMT)     \
     if (!done_) {                                                                     \
       g2::set_error("robot kind / dof combination is not instantiated");              \
       return GPMP2MI_ERR_UNSUPPORTED;                                                 \

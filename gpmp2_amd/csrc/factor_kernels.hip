@@ -61,10 +61,10 @@ int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, do
 }
 
 // --------------------------------------------------------------------------- sphere centres
-template <int KIND, int AD>
+template <int KIND, int AD, int AD2>
 __global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
                                  double* __restrict__ centers, double* __restrict__ J) {
-  using K = Kin<KIND, AD>;
+  using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF;
   __shared__ RobotDev R;
   stage_robot(&R, Rg);
@@ -89,11 +89,11 @@ __global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const d
 // --------------------------------------------------------------------------- link poses + body Jacobians
 // ForwardKinematics::forwardKinematics(jp, none, jpx, none, J_jpx_jp): poses [L][16], J [L][6][D]
 // in GTSAM Pose3 tangent order [omega; v] (body frame)  kinematics/Arm.cpp:105-115.
-template <int KIND, int AD>
+template <int KIND, int AD, int AD2>
 __global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
                      double* __restrict__ poses, double* __restrict__ Jp) {
-  using K = Kin<KIND, AD>;
-  constexpr int D = K::DOF, L = K::NLINKS, BASE = K::BASE;
+  using K = Kin<KIND, AD, AD2>;
+  constexpr int D = K::DOF, L = K::NLINKS;
   __shared__ RobotDev R;
   stage_robot(&R, Rg);
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
@@ -149,66 +149,33 @@ __global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __res
     put_col(0, 0, F, ex, nullptr, true);
     put_col(0, 1, F, ey, nullptr, true);
   } else {
-    Frame F;
-    double vt[3] = {0, 0, 0}, bx[3] = {1, 0, 0}, by[3] = {0, 1, 0};
+    typename K::Axes A;
     const double ez[3] = {0, 0, 1};
-    if constexpr (BASE == 3) {
-      double s, c;
-      sincos(q[2], &s, &c);
-      F.c0[0] = c; F.c0[1] = s; F.c0[2] = 0; F.c1[0] = -s; F.c1[1] = c; F.c1[2] = 0;
-      F.c2[0] = 0; F.c2[1] = 0; F.c2[2] = 1; F.t[0] = q[0]; F.t[1] = q[1]; F.t[2] = 0;
-      vt[0] = q[0]; vt[1] = q[1];
-      bx[0] = c; bx[1] = s; by[0] = -s; by[1] = c;
-      put_pose(0, F);
-      put_col(0, 0, F, bx, nullptr, true);
-      put_col(0, 1, F, by, nullptr, true);
-      put_col(0, 2, F, ez, vt, false);
-      if constexpr (AD > 0) {
-        Frame B, N;
-        frame_from_3x4(R.base, B);
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          N.c0[i] = F.c0[i] * B.c0[0] + F.c1[i] * B.c0[1] + F.c2[i] * B.c0[2];
-          N.c1[i] = F.c0[i] * B.c1[0] + F.c1[i] * B.c1[1] + F.c2[i] * B.c1[2];
-          N.c2[i] = F.c0[i] * B.c2[0] + F.c1[i] * B.c2[1] + F.c2[i] * B.c2[2];
-          N.t[i] = F.t[i] + F.c0[i] * B.t[0] + F.c1[i] * B.t[1] + F.c2[i] * B.t[2];
+    K::walk_links(R, q, A, [&](int link, const Frame& F, auto tag) {
+      constexpr int NC = decltype(tag)::value, FIRST = decltype(tag)::first;
+      put_pose(link, F);
+      if constexpr (K::MOBILE) {
+        put_col(link, 0, F, A.bx, nullptr, true);
+        put_col(link, 1, F, A.by, nullptr, true);
+        put_col(link, 2, F, ez, A.vt, false);
+        if constexpr (K::LIFT == 1 && NC > 3) {
+          const double lz[3] = {0, 0, A.lift_sign};
+          put_col(link, 3, F, lz, nullptr, true);
         }
-        F = N;
       }
-    } else {
-      frame_from_3x4(R.base, F);
-    }
-    if constexpr (AD > 0) {
-      double zax[AD][3], org[AD][3];
 #pragma unroll
-      for (int j = 0; j < AD; j++) {
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-          zax[j][i] = F.c2[i];
-          org[j][i] = F.t[i];
-        }
-        dh_advance(F, q[BASE + j] + R.bias[j], R.a[j], R.d[j], R.ca[j], R.sa[j]);
-        const int link = (BASE == 3) ? j + 1 : j;
-        put_pose(link, F);
-        if constexpr (BASE == 3) {
-          put_col(link, 0, F, bx, nullptr, true);
-          put_col(link, 1, F, by, nullptr, true);
-          put_col(link, 2, F, ez, vt, false);
-        }
-#pragma unroll
-        for (int k = 0; k <= j; k++) put_col(link, BASE + k, F, zax[k], org[k], false);
-      }
-    }
+      for (int k = FIRST; k < NC; k++) put_col(link, k, F, A.zax[k - K::NB], A.org[k - K::NB], false);
+    });
   }
 }
 
 // --------------------------------------------------------------------------- obstacle factors
 // ObstacleSDFFactor / ObstaclePlanarSDFFactor ::evaluateError
-template <int KIND, int AD, int SDIM>
+template <int KIND, int AD, int AD2, int SDIM>
 __global__ void k_obstacle(const RobotDev* __restrict__ Rg, SdfDev sdf, double eps, int M,
                            const double* __restrict__ conf, double* __restrict__ err,
                            double* __restrict__ H1) {
-  using K = Kin<KIND, AD>;
+  using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF;
   __shared__ RobotDev R;
   stage_robot(&R, Rg);
@@ -233,13 +200,13 @@ __global__ void k_obstacle(const RobotDev* __restrict__ Rg, SdfDev sdf, double e
 // ObstacleSDFFactorGP / ObstaclePlanarSDFFactorGP ::evaluateError with
 // GaussianProcessInterpolatorLinear (vector-space robots): conf = l11 c1 + l12 v1 + p11 c2 + p12 v2
 // and H_k = Jerr_conf * (scalar_k I)   (gp/GaussianProcessInterpolatorLinear.h:62-96).
-template <int KIND, int AD, int SDIM>
+template <int KIND, int AD, int AD2, int SDIM>
 __global__ void k_obstacle_gp(const RobotDev* __restrict__ Rg, SdfDev sdf, double eps, GpCoef gc, int M,
                               const double* __restrict__ c1, const double* __restrict__ v1,
                               const double* __restrict__ c2, const double* __restrict__ v2,
                               double* __restrict__ err, double* __restrict__ H1, double* __restrict__ H2,
                               double* __restrict__ H3, double* __restrict__ H4) {
-  using K = Kin<KIND, AD>;
+  using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF;
   __shared__ RobotDev R;
   stage_robot(&R, Rg);
@@ -686,14 +653,14 @@ __global__ void k_joint_limit(int D, const double* __restrict__ down, const doub
 
 int launch_sphere_centers(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* c,
                           double* J, hipStream_t st) {
-  G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_sphere_centers<KIND_, AD_><<<G2_GRID(M)>>>(R, M, conf, c, J)));
+  G2_DISPATCH_ROBOT_H(h, (k_sphere_centers<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, c, J)));
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
 
 int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* poses, double* J,
               hipStream_t st) {
-  G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_fk<KIND_, AD_><<<G2_GRID(M)>>>(R, M, conf, poses, J)));
+  G2_DISPATCH_ROBOT_H(h, (k_fk<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, poses, J)));
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
@@ -701,9 +668,9 @@ int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, d
 int launch_obstacle(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, int M,
                     const double* conf, double* err, double* H1, hipStream_t st) {
   if (s.dim == 3) {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle<KIND_, AD_, 3><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
+    G2_DISPATCH_ROBOT_H(h, (k_obstacle<KIND_, AD_, AD2_, 3><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
   } else {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle<KIND_, AD_, 2><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
+    G2_DISPATCH_ROBOT_H(h, (k_obstacle<KIND_, AD_, AD2_, 2><<<G2_GRID(M)>>>(R, s, eps, M, conf, err, H1)));
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
@@ -713,9 +680,9 @@ int launch_obstacle_gp(const RobotDev& h, const RobotDev* R, const SdfDev& s, do
                        int M, const double* c1, const double* v1, const double* c2, const double* v2,
                        double* err, double* H1, double* H2, double* H3, double* H4, hipStream_t st) {
   if (s.dim == 3) {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle_gp<KIND_, AD_, 3><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
+    G2_DISPATCH_ROBOT_H(h, (k_obstacle_gp<KIND_, AD_, AD2_, 3><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
   } else {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_obstacle_gp<KIND_, AD_, 2><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
+    G2_DISPATCH_ROBOT_H(h, (k_obstacle_gp<KIND_, AD_, AD2_, 2><<<G2_GRID(M)>>>(R, s, eps, gc, M, c1, v1, c2, v2, err, H1, H2, H3, H4)));
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;

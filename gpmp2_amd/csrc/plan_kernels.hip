@@ -29,12 +29,12 @@ namespace g2 {
 #else
 #define G2_LSTAMP(k) do {} while (0)
 #endif
-template <int KIND, int AD, int SDIM>
+template <int KIND, int AD, int AD2, int SDIM>
 __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
                                                    const PlanParams* __restrict__ pp,
                                                    PlanBuffers pb, const double* __restrict__ traj,
                                                    int bufsel, const int* __restrict__ active) {
-  using K = Kin<KIND, AD>;
+  using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF, n = 2 * D, NG = D * (D + 1) / 2;
   const PlanParams& P = *pp;
   const int nchunk = P.Ppad / 64;
@@ -219,9 +219,9 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   // DESIGN.md section 4.)
   const dim3 grid(hp.B * (hp.Ppad / 64)), block(64);
   if (sdf.dim == 3) {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
   } else {
-    G2_DISPATCH_ROBOT(h.kind, h.arm_dof, (k_linearize<KIND_, AD_, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;

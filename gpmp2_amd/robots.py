@@ -20,6 +20,7 @@ from typing import List, Sequence
 import numpy as np
 
 ROBOT_ARM, ROBOT_POINT, ROBOT_POSE2_MOBILE_BASE, ROBOT_POSE2_MOBILE_ARM = 0, 1, 2, 3
+ROBOT_POSE2_MOBILE_2ARMS, ROBOT_POSE2_MOBILE_VETLIN_ARM, ROBOT_POSE2_MOBILE_VETLIN_2ARMS = 4, 5, 6
 
 
 def pose3(R=None, t=(0.0, 0.0, 0.0)) -> np.ndarray:
@@ -96,6 +97,58 @@ class Pose2MobileArm:
         return self.arm.dof() + 1
 
 
+def _T(x):
+    return np.eye(4) if x is None else np.asarray(x, dtype=np.float64).reshape(4, 4).copy()
+
+
+class Pose2Mobile2Arms:
+    """gpmp2::Pose2Mobile2Arms (kinematics/Pose2Mobile2Arms.cpp:18-108): state [x, y, theta, q_arm1, q_arm2];
+    links: vehicle base, arm-1 links, arm-2 links"""
+
+    def __init__(self, arm1: Arm, arm2: Arm, base_T_arm1=None, base_T_arm2=None):
+        self.arm1, self.arm2 = arm1, arm2
+        self.base_T_arm1, self.base_T_arm2 = _T(base_T_arm1), _T(base_T_arm2)
+
+    def dof(self):
+        return self.arm1.dof() + self.arm2.dof() + 3
+
+    def nr_links(self):
+        return self.arm1.dof() + self.arm2.dof() + 1
+
+
+class Pose2MobileVetLinArm:
+    """gpmp2::Pose2MobileVetLinArm (kinematics/Pose2MobileVetLinArm.cpp:18-108): state
+    [x, y, theta, lift, q_arm]; links: vehicle base, torso, arm links"""
+
+    def __init__(self, arm: Arm, base_T_torso=None, torso_T_arm=None, reverse_linact=False):
+        self.arm = arm
+        self.base_T_torso, self.torso_T_arm = _T(base_T_torso), _T(torso_T_arm)
+        self.reverse_linact = bool(reverse_linact)
+
+    def dof(self):
+        return self.arm.dof() + 4
+
+    def nr_links(self):
+        return self.arm.dof() + 2
+
+
+class Pose2MobileVetLin2Arms:
+    """gpmp2::Pose2MobileVetLin2Arms (kinematics/Pose2MobileVetLin2Arms.cpp:20-114): state
+    [x, y, theta, lift, q_arm1, q_arm2]; links: vehicle base, torso, arm-1 links, arm-2 links"""
+
+    def __init__(self, arm1: Arm, arm2: Arm, base_T_torso=None, torso_T_arm1=None, torso_T_arm2=None,
+                 reverse_linact=False):
+        self.arm1, self.arm2 = arm1, arm2
+        self.base_T_torso, self.torso_T_arm1, self.torso_T_arm2 = _T(base_T_torso), _T(torso_T_arm1), _T(torso_T_arm2)
+        self.reverse_linact = bool(reverse_linact)
+
+    def dof(self):
+        return self.arm1.dof() + self.arm2.dof() + 4
+
+    def nr_links(self):
+        return self.arm1.dof() + self.arm2.dof() + 2
+
+
 class RobotModel:
     """FK model + body spheres -> flat description consumed by the C ABI."""
 
@@ -128,29 +181,48 @@ class RobotModel:
             return ROBOT_POSE2_MOBILE_BASE
         if isinstance(self.fk, Pose2MobileArm):
             return ROBOT_POSE2_MOBILE_ARM
+        if isinstance(self.fk, Pose2Mobile2Arms):
+            return ROBOT_POSE2_MOBILE_2ARMS
+        if isinstance(self.fk, Pose2MobileVetLinArm):
+            return ROBOT_POSE2_MOBILE_VETLIN_ARM
+        if isinstance(self.fk, Pose2MobileVetLin2Arms):
+            return ROBOT_POSE2_MOBILE_VETLIN_2ARMS
         raise TypeError("unknown FK model")
 
     def flat(self):
         """dict of contiguous numpy arrays in the layout of gpmp2mi_robot_desc."""
         fk = self.fk
-        arm = fk if isinstance(fk, Arm) else (fk.arm if isinstance(fk, Pose2MobileArm) else None)
-        base = np.eye(4)
+        eye = np.eye(4)
+        arms, base, base2, base3, rev = [], eye, eye, eye, False
         if isinstance(fk, Arm):
-            base = fk.base_pose
+            arms, base = [fk], fk.base_pose
         elif isinstance(fk, Pose2MobileArm):
-            base = fk.base_T_arm
-        ad = arm.dof() if arm is not None else 0
-        z = np.zeros(max(ad, 1))
+            arms, base = [fk.arm], fk.base_T_arm
+        elif isinstance(fk, Pose2Mobile2Arms):
+            arms, base, base2 = [fk.arm1, fk.arm2], fk.base_T_arm1, fk.base_T_arm2
+        elif isinstance(fk, Pose2MobileVetLinArm):
+            arms, base, base2, rev = [fk.arm], fk.base_T_torso, fk.torso_T_arm, fk.reverse_linact
+        elif isinstance(fk, Pose2MobileVetLin2Arms):
+            arms, base, base2, base3, rev = ([fk.arm1, fk.arm2], fk.base_T_torso, fk.torso_T_arm1, fk.torso_T_arm2,
+                                             fk.reverse_linact)
+        ad = sum(a.dof() for a in arms)
+        z = np.zeros(1)
+
+        def cat(name):
+            return np.ascontiguousarray(np.concatenate([np.asarray(getattr(a, name), dtype=np.float64) for a in arms])
+                                        if arms else z)
+
         return dict(
             kind=self.kind, dof=fk.dof(), arm_dof=ad,
-            a=np.ascontiguousarray(arm.a if arm is not None else z),
-            alpha=np.ascontiguousarray(arm.alpha if arm is not None else z),
-            d=np.ascontiguousarray(arm.d if arm is not None else z),
-            theta_bias=np.ascontiguousarray(arm.theta_bias if arm is not None else z),
+            a=cat("a"), alpha=cat("alpha"), d=cat("d"), theta_bias=cat("theta_bias"),
             base_pose=np.ascontiguousarray(base, dtype=np.float64).reshape(16),
             sphere_link=np.ascontiguousarray([s.link_id for s in self.spheres], dtype=np.int32),
             sphere_radius=np.ascontiguousarray([s.radius for s in self.spheres], dtype=np.float64),
             sphere_center=np.ascontiguousarray([list(s.center) for s in self.spheres], dtype=np.float64).reshape(-1),
+            arm2_dof=arms[1].dof() if len(arms) == 2 else 0,
+            base_pose2=np.ascontiguousarray(base2, dtype=np.float64).reshape(16),
+            base_pose3=np.ascontiguousarray(base3, dtype=np.float64).reshape(16),
+            reverse_linact=int(rev),
         )
 
 
@@ -158,6 +230,9 @@ ArmModel = RobotModel
 PointRobotModel = RobotModel
 Pose2MobileBaseModel = RobotModel
 Pose2MobileArmModel = RobotModel
+Pose2Mobile2ArmsModel = RobotModel
+Pose2MobileVetLinArmModel = RobotModel
+Pose2MobileVetLin2ArmsModel = RobotModel
 
 
 def _spheres(rows):

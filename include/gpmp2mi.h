@@ -63,14 +63,19 @@ enum {
   GPMP2MI_ROBOT_ARM = 0,               /* gpmp2::ArmModel          kinematics/Arm.h:27-146 */
   GPMP2MI_ROBOT_POINT = 1,             /* gpmp2::PointRobotModel   kinematics/PointRobot.cpp:15-49 */
   GPMP2MI_ROBOT_POSE2_MOBILE_BASE = 2, /* gpmp2::Pose2MobileBaseModel kinematics/Pose2MobileBase.cpp:20-55 */
-  GPMP2MI_ROBOT_POSE2_MOBILE_ARM = 3   /* gpmp2::Pose2MobileArmModel  kinematics/Pose2MobileArm.cpp:30-108 */
+  GPMP2MI_ROBOT_POSE2_MOBILE_ARM = 3,  /* gpmp2::Pose2MobileArmModel  kinematics/Pose2MobileArm.cpp:30-108 */
+  GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS = 4,        /* gpmp2::Pose2Mobile2ArmsModel kinematics/Pose2Mobile2Arms.cpp:32-108 */
+  GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM = 5,   /* gpmp2::Pose2MobileVetLinArmModel kinematics/Pose2MobileVetLinArm.cpp:31-108 */
+  GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS = 6  /* gpmp2::Pose2MobileVetLin2ArmsModel kinematics/Pose2MobileVetLin2Arms.cpp:36-114 */
 };
 
 /* POD description of RobotModel<FK> = FK + BodySphereVector (kinematics/RobotModel.h:20-90). */
 typedef struct gpmp2mi_robot_desc {
   int kind;                   /* GPMP2MI_ROBOT_* */
-  int dof;                    /* total dof (POINT: 2; MOBILE_BASE: 3; MOBILE_ARM: 3 + arm_dof) */
-  int arm_dof;                /* number of DH joints (0 for POINT / MOBILE_BASE) */
+  int dof;                    /* total dof (POINT: 2; MOBILE_BASE: 3; MOBILE_ARM / 2ARMS: 3 + arm_dof;
+                                 VETLIN_*: 4 + arm_dof, state [x, y, theta, lift, q...]) */
+  int arm_dof;                /* number of DH joints, both arms together (0 for POINT / MOBILE_BASE);
+                                 the DH arrays list arm 1 first, then arm 2 */
   const double* a;            /* [arm_dof] DH a        (Arm ctor, kinematics/Arm.cpp:15-28) */
   const double* alpha;        /* [arm_dof] DH alpha */
   const double* d;            /* [arm_dof] DH d */
@@ -81,6 +86,14 @@ typedef struct gpmp2mi_robot_desc {
   const int* sphere_link;     /* [S] link id (BodySphere::link_id) */
   const double* sphere_radius;/* [S] */
   const double* sphere_center;/* [S][3] centre in the link frame */
+  /* two-arm / vertical-lift robots (zero / identity otherwise).  Link order: vehicle base,
+   * [torso], arm-1 links, arm-2 links. */
+  int arm2_dof;               /* DH joints of the second arm (the last arm2_dof of arm_dof) */
+  double base_pose2[16];      /* 2ARMS: base_T_arm2 (base_pose = base_T_arm1).
+                                 VETLIN_ARM: torso_T_arm (base_pose = base_T_torso).
+                                 VETLIN_2ARMS: torso_T_arm1 (base_pose = base_T_torso) */
+  double base_pose3[16];      /* VETLIN_2ARMS: torso_T_arm2 */
+  int reverse_linact;         /* VETLIN_*: lift moves the torso down (liftBasePose3, mobileBaseUtils.cpp:51-82) */
 } gpmp2mi_robot_desc;
 
 typedef struct gpmp2mi_robot gpmp2mi_robot;

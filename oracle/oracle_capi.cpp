@@ -21,6 +21,10 @@ static void fill_robot(const gpmp2mi_robot_desc* d, Robot& R) {
   if (d->theta_bias) R.bias.assign(d->theta_bias, d->theta_bias + d->arm_dof);
   else R.bias.assign(d->arm_dof, 0.0);
   std::memcpy(R.base, d->base_pose, sizeof(R.base));
+  R.arm2_dof = d->arm2_dof;
+  std::memcpy(R.base2, d->base_pose2, sizeof(R.base2));
+  std::memcpy(R.base3, d->base_pose3, sizeof(R.base3));
+  R.reverse_linact = d->reverse_linact != 0;
   R.sph_link.assign(d->sphere_link, d->sphere_link + d->nr_spheres);
   R.sph_r.assign(d->sphere_radius, d->sphere_radius + d->nr_spheres);
   R.sph_c.assign(d->sphere_center, d->sphere_center + 3 * d->nr_spheres);

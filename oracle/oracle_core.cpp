@@ -522,16 +522,17 @@ static void dh_const(double a, double alpha, double d, double* C) {
 
 // Arm::forwardKinematics, pose part   kinematics/Arm.cpp:31-143 (jv == none)
 // poses [dof][16]; Jp [dof][6][ldJ] written into columns [col0, col0+dof)
+// joints [j0, j0 + n) of the DH table (n < 0: all of them)
 static void arm_fk(const Robot& R, const double* base, const double* q, double* poses, double* Jp,
-                   int ldJ, int col0) {
-  const int n = R.arm_dof;
+                   int ldJ, int col0, int j0 = 0, int n = -1) {
+  if (n < 0) n = R.arm_dof;
   std::vector<double> H(16 * n), dH(16 * n), Ho(16 * (n + 1)), Hoinv(16 * (n + 1));
   std::memcpy(&Ho[0], base, 16 * sizeof(double));
   m4inv_rigid(&Ho[0], &Hoinv[0]);
   for (int i = 1; i <= n; i++) {
     double C[16];
-    dh_const(R.a[i - 1], R.alpha[i - 1], R.d[i - 1], C);
-    const double th = q[i - 1] + (R.bias.empty() ? 0.0 : R.bias[i - 1]);
+    dh_const(R.a[j0 + i - 1], R.alpha[j0 + i - 1], R.d[j0 + i - 1], C);
+    const double th = q[i - 1] + (R.bias.empty() ? 0.0 : R.bias[j0 + i - 1]);
     const double c = std::cos(th), s = std::sin(th);
     const double Rz[16] = {c, -s, 0, 0, s, c, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     m4mul(Rz, C, &H[16 * (i - 1)]);                       // getH        Arm.h:101-103
@@ -590,6 +591,86 @@ static void base_pose3(const double* p2, double* T, double* J /*6x3 or null*/) {
     J[2 * 3 + 2] = 1.0;  // Rot3::ExpmapDerivative((0,0,theta)).col(2) = e_z
     J[3 * 3 + 0] = 1.0;
     J[4 * 3 + 1] = 1.0;
+  }
+}
+
+// H_out (6 x nb) = Ad(T^-1) * H_in : Jacobian of parent.compose(T) w.r.t. the parent's parameters
+static void compose_jac(const double* T, const double* Hin, int nb, double* Hout) {
+  double inv[16], Ad[36];
+  m4inv_rigid(T, inv);
+  pose3_adjoint(inv, Ad);
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < nb; j++) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += Ad[i * 6 + k] * Hin[k * nb + j];
+      Hout[i * nb + j] = s;
+    }
+}
+
+// vehicle base [+ vertical lift torso] + one or two arms
+static void tree_fk(const Robot& R, const double* conf, double* poses, double* Jpose) {
+  const int D = R.dof;
+  const bool lift = R.has_lift();
+  const int nb = lift ? 4 : 3;  // parameters the arm bases depend on
+  const int A2 = (R.kind == MOBILE_VETLIN_ARM) ? 0 : R.arm2_dof, A1 = R.arm_dof - A2;
+  double veh[16], Hveh[18];
+  base_pose3(conf, veh, Hveh);
+  std::memcpy(poses, veh, sizeof(veh));
+  if (Jpose)
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 3; j++) Jpose[i * D + j] = Hveh[i * 3 + j];
+  double parent[16], Hparent[24];
+  int first_arm_link = 1;
+  if (lift) {
+    // liftBasePose3  kinematics/mobileBaseUtils.cpp:51-82: lift_pose.compose(veh.compose(base_T_torso))
+    double armbase[16], Harmbase[18];
+    m4mul(veh, R.base, armbase);
+    compose_jac(R.base, Hveh, 3, Harmbase);
+    const double lz = R.reverse_linact ? -conf[3] : conf[3];
+    std::memcpy(parent, armbase, sizeof(armbase));
+    parent[11] += lz;  // pure world-z translation on the left
+    // Hcomp2 = I ; Hcomp1 = Ad(armbase^-1), its column 5 = d/d(lift z)
+    double inv[16], Ad[36];
+    m4inv_rigid(armbase, inv);
+    pose3_adjoint(inv, Ad);
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j < 3; j++) Hparent[i * 4 + j] = Harmbase[i * 3 + j];
+      Hparent[i * 4 + 3] = R.reverse_linact ? -Ad[i * 6 + 5] : Ad[i * 6 + 5];
+    }
+    std::memcpy(poses + 16, parent, sizeof(parent));
+    if (Jpose)
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 4; j++) Jpose[(size_t)6 * D + i * D + j] = Hparent[i * 4 + j];
+    first_arm_link = 2;
+  } else {
+    std::memcpy(parent, veh, sizeof(veh));
+    for (int i = 0; i < 18; i++) Hparent[i] = Hveh[i];
+  }
+  const double* T_arm[2] = {lift ? R.base2 : R.base, lift ? R.base3 : R.base2};
+  const int na[2] = {A1, A2}, j0[2] = {0, A1};
+  int link = first_arm_link;
+  for (int a = 0; a < 2; a++) {
+    if (na[a] == 0) continue;
+    double armb[16], Harm[24];
+    m4mul(parent, T_arm[a], armb);
+    compose_jac(T_arm[a], Hparent, nb, Harm);
+    arm_fk(R, armb, conf + nb + j0[a], poses + 16 * link, Jpose ? Jpose + (size_t)link * 6 * D : nullptr, D,
+           nb + j0[a], j0[a], na[a]);
+    if (Jpose)
+      for (int l = 0; l < na[a]; l++) {  // "see compose's jacobian": Ad(link^-1 * arm_base) * Harm_base
+        double inv[16], T[16], Ad[36];
+        m4inv_rigid(poses + 16 * (link + l), inv);
+        m4mul(inv, armb, T);
+        pose3_adjoint(T, Ad);
+        double* J = Jpose + (size_t)(link + l) * 6 * D;
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < nb; j++) {
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += Ad[i * 6 + k] * Harm[k * nb + j];
+            J[i * D + j] = s;
+          }
+      }
+    link += na[a];
   }
 }
 
@@ -652,6 +733,11 @@ void forward_kinematics(const Robot& R, const double* conf, double* poses, doubl
             }
         }
     } break;
+    case MOBILE_2ARMS:         // kinematics/Pose2Mobile2Arms.cpp:32-108
+    case MOBILE_VETLIN_ARM:    // kinematics/Pose2MobileVetLinArm.cpp:31-108
+    case MOBILE_VETLIN_2ARMS:  // kinematics/Pose2MobileVetLin2Arms.cpp:36-114
+      tree_fk(R, conf, poses, Jpose);
+      break;
   }
 }
 

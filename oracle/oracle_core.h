@@ -40,19 +40,23 @@ Mat operator-(const Mat& A, const Mat& B);
 Mat operator*(double s, const Mat& A);
 
 // ---------------------------------------------------------------- robot / sdf descriptions
-enum RobotKind { ARM = 0, POINT = 1, MOBILE_BASE = 2, MOBILE_ARM = 3 };
+enum RobotKind { ARM = 0, POINT = 1, MOBILE_BASE = 2, MOBILE_ARM = 3, MOBILE_2ARMS = 4, MOBILE_VETLIN_ARM = 5, MOBILE_VETLIN_2ARMS = 6 };
 
 struct Robot {
   int kind = ARM, dof = 0, arm_dof = 0;
   std::vector<double> a, alpha, d, bias;
   double base[16];  // row-major 4x4
+  int arm2_dof = 0;       // two-arm robots: the last arm2_dof DH joints belong to arm 2
+  double base2[16], base3[16];
+  bool reverse_linact = false;
+  bool has_lift() const { return kind == MOBILE_VETLIN_ARM || kind == MOBILE_VETLIN_2ARMS; }
   std::vector<int> sph_link;
   std::vector<double> sph_r, sph_c;  // radius [S], centre [S][3]
   int nr_links() const {
-    return kind == ARM ? arm_dof : kind == POINT ? 1 : kind == MOBILE_BASE ? 1 : arm_dof + 1;
+    return kind == ARM ? arm_dof : kind == POINT ? 1 : kind == MOBILE_BASE ? 1 : arm_dof + 1 + (has_lift() ? 1 : 0);
   }
   int nr_spheres() const { return (int)sph_r.size(); }
-  bool is_lie() const { return kind == MOBILE_BASE || kind == MOBILE_ARM; }
+  bool is_lie() const { return kind >= MOBILE_BASE; }
 };
 
 struct Sdf {

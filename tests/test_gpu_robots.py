@@ -1,0 +1,139 @@
+"""GPU parity for the two-arm / vertical-lift mobile robots (Pose2Mobile2Arms, Pose2MobileVetLinArm,
+Pose2MobileVetLin2Arms): forward kinematics against the reference's known answers
+(kinematics/tests/testPose2Mobile2Arms.cpp, testPose2MobileVetLinArm.cpp, testPose2MobileVetLin2Arms.cpp),
+sphere centres / obstacle factors / whole plans against the oracle."""
+import numpy as np
+import pytest
+
+import gpmp2_amd as g
+from gpmp2_amd import problems
+from gpmp2_amd.settings import TrajOptimizerSetting
+from helpers import num, tree_robot_from_golden, vec
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["pose2_mobile_2arms", "pose2_mobile_vetlin_arm", "pose2_mobile_vetlin_2arms"]
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_tree_robot_fk_and_spheres(engine, oracle, golden, key):
+    d = golden[key]
+    model = tree_robot_from_golden(d, key)
+    r, ro = engine.robot(model), oracle.robot(model)
+    L = model.fk_model().nr_links()
+    for c in d["cases"]:
+        poses, _ = engine.forward_kinematics(r, vec(c["q"]))
+        for l in range(L):
+            np.testing.assert_allclose(poses[0, l], g.pose3(g.rot_yaw(num(c["yaw"][l])), c["xyz"][l]), atol=d["tol"])
+    rng = np.random.default_rng(7)
+    q = rng.uniform(-3, 3, size=(50, model.dof()))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-11)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-11)
+    if key == "pose2_mobile_vetlin_2arms":                     # the reference's random base poses, :122-150
+        m2 = tree_robot_from_golden(d, key, random_bases=True)
+        a = engine.forward_kinematics(engine.robot(m2), vec(d["random"]["q"]))
+        b = oracle.forward_kinematics(oracle.robot(m2), vec(d["random"]["q"]))
+        np.testing.assert_allclose(a[0], b[0], atol=1e-10)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-10)
+    if key == "pose2_mobile_vetlin_arm":
+        d2 = dict(d)
+        d2["reverse_linact"] = True
+        m3 = tree_robot_from_golden(d2, key)
+        a, b = engine.sphere_centers(engine.robot(m3), q), oracle.sphere_centers(oracle.robot(m3), q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-11)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-11)
+
+
+SCALE = 4.0   # the desk scene blown up to [-4, 4]^3 so that the metre-sized test robots live inside it
+
+
+def _small_field():
+    origin, cell, data = problems.small3d_sdf(40)
+    return list(np.array(origin) * SCALE), cell * SCALE, data * SCALE
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_tree_robot_obstacle_factors(engine, oracle, golden, key):
+    d = golden[key]
+    model = tree_robot_from_golden(d, key)
+    r, ro = engine.robot(model), oracle.robot(model)
+    origin, cell, data = _small_field()
+    s, so = engine.sdf(origin, cell, data), oracle.sdf(origin, cell, data)
+    rng = np.random.default_rng(11)
+    D = model.dof()
+    q1 = rng.uniform(-1.0, 1.0, size=(40, D))
+    q2 = q1 + 0.2 * rng.normal(size=q1.shape)
+    v1, v2 = rng.normal(size=q1.shape), rng.normal(size=q1.shape)
+    a, b = engine.obstacle_factor(r, s, 0.8, q1), oracle.obstacle_factor(ro, so, 0.8, q1)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-8)
+    assert (b[0] > 0).any()
+    a = engine.obstacle_gp_factor(r, s, 0.8, None, 0.5, 0.2, q1, v1, q2, v2)
+    b = oracle.obstacle_gp_factor(ro, so, 0.8, None, 0.5, 0.2, q1, v1, q2, v2)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_allclose(x, y, atol=1e-8)
+
+
+def _tree_problem(model, N=12, inter=2, opt="GN"):
+    D = model.dof()
+    origin, cell, data = _small_field()
+    st = TrajOptimizerSetting(D)
+    st.set_total_step(N)
+    st.set_total_time(3.0)
+    st.set_obs_check_inter(inter)
+    st.set_cost_sigma(0.2)
+    st.set_epsilon(0.6)
+    st.set_conf_prior_model(1e-3)
+    st.set_vel_prior_model(1e-3)
+    st.set_Qc_model(np.eye(D))
+    {"GN": st.setGaussNewton, "LM": st.setLM, "DOGLEG": st.setDogleg}[opt]()
+    st.set_max_iter(30)
+    st.set_rel_thresh(1e-4)
+    start = np.zeros(D)
+    start[:3] = [-1.5, -1.0, 0.3]
+    end = np.zeros(D)
+    end[:3] = [1.5, 1.2, -0.4]
+    end[3:] = np.linspace(0.3, 0.9, D - 3)
+    init = np.zeros((1, N + 1, 2 * D))
+    for i in range(N + 1):
+        init[0, i, :D] = start * (N - i) / N + end * i / N
+    init[0, :, D:] = (end - start)[None, :] / 3.0
+    z = np.zeros((1, D))
+    return problems.Problem("tree", model, origin, cell, data, st, start[None], z.copy(), end[None], z.copy(), init)
+
+
+@pytest.mark.parametrize("key,opt", [("pose2_mobile_2arms", "GN"), ("pose2_mobile_2arms", "DOGLEG"),
+                                     ("pose2_mobile_vetlin_arm", "GN"), ("pose2_mobile_vetlin_arm", "LM")])
+def test_tree_robot_plans(engine, oracle, golden, key, opt):
+    """whole plans (dof 7 and 6): linearization and solve vs the oracle, incl. GP-interpolated obstacle
+    factors on the Lie path"""
+    model = tree_robot_from_golden(golden[key], key)
+    p = _tree_problem(model, opt=opt)
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    rng = np.random.default_rng(19)
+    traj = p.init + 0.05 * rng.normal(size=p.init.shape)
+    a = engine.linearize(r, s, p.setting, *args, traj)
+    b = oracle.linearize(ro, so, p.setting, *args, traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    res = engine.batch_optimize(r, s, p.setting, *args, p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+def test_vetlin_2arms_plan_is_rejected_cleanly(engine, golden):
+    """dof 8 > 7: factor level works (above), the block solver does not have tiles for it yet"""
+    model = tree_robot_from_golden(golden["pose2_mobile_vetlin_2arms"], "pose2_mobile_vetlin_2arms")
+    p = _tree_problem(model)
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    with pytest.raises(g.engine.Gpmp2miError) as e:
+        engine.plan(r, s, p.setting, 1)
+    assert e.value.code == 4                                   # GPMP2MI_ERR_UNSUPPORTED

@@ -535,3 +535,52 @@ def test_workspace_orientation_and_pose(oracle, golden):
         err, H = oracle.workspace_prior_factor(wam, mode, 6, des, qq)
         Hn = numeric_jacobian(lambda x: oracle.workspace_prior_factor(wam, mode, 6, des, x, jac=False)[0][0], qq, 1e-6)
         np.testing.assert_allclose(H[0], Hn, atol=1e-5)
+
+
+# ------------------------------------------------------------------ two-arm / vertical-lift mobile robots
+from helpers import tree_robot_from_golden  # noqa: E402
+
+
+def _check_tree_fk(oracle, model, q):
+    r = oracle.robot(model)
+    L, D = model.fk_model().nr_links(), model.dof()
+    poses, J = oracle.forward_kinematics(r, q)
+    for l in range(L):
+        Jn = np.zeros((6, D))
+        for k in range(D):
+            dq = np.zeros(D)
+            dq[k] = 1e-6
+            Pp, _ = oracle.forward_kinematics(r, _p2v_retract(q, dq))
+            Pm, _ = oracle.forward_kinematics(r, _p2v_retract(q, -dq))
+            Jn[:, k] = (_pose_local(poses[0, l], Pp[0, l]) - _pose_local(poses[0, l], Pm[0, l])) / 2e-6
+        np.testing.assert_allclose(J[0, l], Jn, atol=1e-6)
+    if model.nr_body_spheres():
+        ctr, Jc = oracle.sphere_centers(r, q)
+        Jn = _num_jac_lie(lambda x: oracle.sphere_centers(r, x)[0][0], q, lie_in=True)
+        np.testing.assert_allclose(Jc[0], Jn, atol=1e-7)
+
+
+@pytest.mark.parametrize("key", ["pose2_mobile_2arms", "pose2_mobile_vetlin_arm", "pose2_mobile_vetlin_2arms"])
+def test_tree_robot_fk_known_answers(oracle, golden, key):
+    d = golden[key]                                            # testPose2Mobile2Arms.cpp etc.
+    model = tree_robot_from_golden(d, key)
+    r = oracle.robot(model)
+    for c in d["cases"]:
+        poses, _ = oracle.forward_kinematics(r, vec(c["q"]))
+        for l in range(model.fk_model().nr_links()):
+            np.testing.assert_allclose(poses[0, l], g.pose3(g.rot_yaw(num(c["yaw"][l])), c["xyz"][l]), atol=d["tol"])
+        _check_tree_fk(oracle, model, vec(c["q"]))
+    if key == "pose2_mobile_vetlin_2arms":                     # "random to test jacobians", :122-150
+        _check_tree_fk(oracle, tree_robot_from_golden(d, key, random_bases=True), vec(d["random"]["q"]))
+    else:
+        _check_tree_fk(oracle, model, vec(d["random_q"]))
+
+
+def test_vetlin_reverse_linact(oracle, golden):
+    d = dict(golden["pose2_mobile_vetlin_arm"])
+    d["reverse_linact"] = True
+    model = tree_robot_from_golden(d, "pose2_mobile_vetlin_arm")
+    q = vec(d["cases"][1]["q"])
+    poses, _ = oracle.forward_kinematics(oracle.robot(model), q)
+    assert abs(poses[0, 1][2, 3] + 1.5) < 1e-12 and abs(poses[0, 2][2, 3] - 0.5) < 1e-12   # torso moved down
+    _check_tree_fk(oracle, model, q)
