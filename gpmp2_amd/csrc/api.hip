@@ -210,8 +210,7 @@ struct gpmp2mi_plan {
   PlanParams hp;
   PlanBuffers pb;
   std::vector<void*> allocs;
-  int* h_nactive = nullptr;  // pinned [2]
-  hipEvent_t ev[2] = {nullptr, nullptr};
+  int* h_flags = nullptr;    // pinned + device-mapped [n_active_len]: per-pass active count, -1 = not yet known
   KernelTimer timer;
   bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
   int n_active_len = 0;
@@ -939,9 +938,9 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.n_active, p->n_active_len));
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
   G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
-  G2_HIP(hipHostMalloc((void**)&p->h_nactive, 2 * sizeof(int), hipHostMallocDefault));
-  G2_HIP(hipEventCreateWithFlags(&p->ev[0], hipEventDisableTiming));
-  G2_HIP(hipEventCreateWithFlags(&p->ev[1], hipEventDisableTiming));
+  G2_HIP(hipHostMalloc((void**)&p->h_flags, p->n_active_len * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  G2_HIP(hipHostGetDevicePointer((void**)&pb.host_flags, p->h_flags, 0));
+  G2_TRY(plan_alloc(p.get(), &pb.done, p->n_active_len));
   *out = p.release();
   return GPMP2MI_OK;
 }
@@ -949,9 +948,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
 void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
-  if (p->h_nactive) (void)hipHostFree(p->h_nactive);
-  for (auto e : p->ev)
-    if (e) (void)hipEventDestroy(e);
+  if (p->h_flags) (void)hipHostFree(p->h_flags);
   delete p;
 }
 
@@ -986,11 +983,36 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   return plan_run(p, st);
 }
 
+// Active-trajectory count of a finished pass.  The closing kernel of every pass publishes it to a pinned,
+// device-mapped flag (publish_pass_count), so there is no copy command or event in the stream; the host spins
+// on the flag and falls back to the stream state if the flag never arrives (a faulted kernel).
+static int wait_pass_count(gpmp2mi_plan* p, int pass, hipStream_t st, int* count) {
+  volatile int* flag = p->h_flags + pass;
+  for (long spin = 0;; spin++) {
+    const int v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+    if (v >= 0) {
+      *count = v;
+      return GPMP2MI_OK;
+    }
+    if ((spin & 0xfff) == 0xfff) {
+      const hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) {  // everything enqueued has run: the flag must be there now
+        const int w = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+        G2_CHECK(w >= 0, GPMP2MI_ERR_HIP, "pass count was never published");
+        *count = w;
+        return GPMP2MI_OK;
+      }
+      if (e != hipErrorNotReady) G2_HIP(e);
+    }
+  }
+}
+
 // the optimizer driver: `cur` holds the starting values
 static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
   const PlanParams& P = p->hp;
   PlanBuffers& pb = p->pb;
   p->timer.reset();
+  for (int k = 0; k < p->n_active_len; k++) p->h_flags[k] = -1;  // the previous run has drained (stream sync below)
   G2_TRY(launch_plan_reset(P, pb, st));
   const int iter_cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
   if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn) {
@@ -1000,7 +1022,6 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
     // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
     const int max_pass = iter_cap + 1;
     for (int pass = 0; pass < max_pass; pass++) {
-      const int slot = pass & 1;
       p->timer.begin("linearize", st);
       G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, 0, pb.active, st));
       p->timer.begin("assemble", st);
@@ -1008,11 +1029,10 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
       p->timer.begin("gn_step_cr", st);
       G2_TRY(launch_gn_step_cr(P, pb, pass, st));
       p->timer.close(st);
-      G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
-      G2_HIP(hipEventRecord(p->ev[slot], st));
       if (pass >= 1) {
-        G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
-        if (p->h_nactive[slot ^ 1] == 0) break;
+        int cnt = 0;
+        G2_TRY(wait_pass_count(p, pass - 1, st, &cnt));
+        if (cnt == 0) break;
       }
     }
   } else {
@@ -1026,7 +1046,6 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
     G2_TRY(launch_decide(P, pb, 0, true, st));
     p->timer.close(st);
     for (int pass = 1; pass < max_pass; pass++) {
-      const int slot = pass & 1;
       p->timer.begin("assemble", st);
       G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
       if (P.opt_type == GPMP2MI_OPT_DOGLEG) {
@@ -1040,11 +1059,10 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
       p->timer.begin("decide", st);
       G2_TRY(launch_decide(P, pb, pass, false, st));
       p->timer.close(st);
-      G2_HIP(hipMemcpyAsync(&p->h_nactive[slot], pb.n_active + pass, sizeof(int), hipMemcpyDeviceToHost, st));
-      G2_HIP(hipEventRecord(p->ev[slot], st));
       if (pass >= 2) {
-        G2_HIP(hipEventSynchronize(p->ev[slot ^ 1]));
-        if (p->h_nactive[slot ^ 1] == 0) break;
+        int cnt = 0;
+        G2_TRY(wait_pass_count(p, pass - 1, st, &cnt));
+        if (cnt == 0) break;
       }
     }
   }

@@ -354,10 +354,8 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
 }
 
 template <int D>
-__global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* __restrict__ pp,
-                                                               PlanBuffers pb, int pass) {
+__device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuffers& pb, int pass) {
   constexpr int n = 2 * D;
-  const PlanParams& P = *pp;
   const int b = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   if (!pb.active[b]) return;
   const int N = P.N;
@@ -456,6 +454,12 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
     pb.iters[b] += 1;
     atomicAdd(pb.n_active + pass, 1);
   }
+}
+template <int D>
+__global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* __restrict__ pp,
+                                                               PlanBuffers pb, int pass) {
+  gn_step_body<D>(*pp, pb, pass);
+  if (threadIdx.x == 0) publish_pass_count(pb, pass);
 }
 
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {

@@ -75,6 +75,8 @@ struct PlanBuffers {
   int* notspd;             // [B] set when a level-1 pivot (k_assemble) was not positive
   double* epart;           // [B][Npad] per-block share of the graph error (k_assemble)
   int* n_active;           // [max_pass] trajectories that iterated in each pass
+  int* done;               // [max_pass] workgroups of the pass-closing kernel that have finished
+  int* host_flags;         // [max_pass] pinned, device-mapped: n_active[pass] once the pass is complete, else -1
   unsigned long long* stamps;  // [B][64] s_memtime stamps (diagnostic builds only)
 };
 

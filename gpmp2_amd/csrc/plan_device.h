@@ -84,4 +84,15 @@ __device__ __forceinline__ bool check_convergence(double rel, double abs_, doubl
 }
 
 
+// Called by one thread of every workgroup of the kernel that closes a pass, after its own work: the last
+// workgroup to arrive publishes the pass's active count to the host-mapped flag array, so the host
+// driver learns it without a copy command or an event in the stream.
+__device__ __forceinline__ void publish_pass_count(const PlanBuffers& pb, int pass) {
+  __threadfence();
+  if (atomicAdd(pb.done + pass, 1) == (int)gridDim.x - 1) {
+    const int v = atomicAdd(pb.n_active + pass, 0);
+    __hip_atomic_store(pb.host_flags + pass, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace g2

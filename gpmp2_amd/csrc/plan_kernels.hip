@@ -250,7 +250,7 @@ __global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) 
   const PlanParams& P = *pp;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b == 0)
-    for (int k = 0; k < P.max_pass; k++) pb.n_active[k] = 0;
+    for (int k = 0; k < P.max_pass; k++) pb.n_active[k] = pb.done[k] = 0;
   if (b >= P.B) return;
   pb.iters[b] = 0;
   pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
@@ -280,8 +280,7 @@ int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t s
 //   DoglegOptimizerImpl::Iterate(ONE_STEP_PER_ITERATION)  (gain ratio rho, trust radius update)
 // followed by the do/while of gpmp2::optimize (checkConvergence, max_iter, no-increase rollback).
 // GTSAM semantics restated from upstream.
-__global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
-  const PlanParams& P = *pp;
+__device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffers& pb, int pass, int init) {
   const int b = blockIdx.x, lane = threadIdx.x;
   if (!pb.active[b]) return;
   const int N = P.N, n = P.n;
@@ -410,6 +409,10 @@ __global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp
     if (action != 0) pb.active[b] = 0;
     else atomicAdd(pb.n_active + pass, 1);
   }
+}
+__global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
+  decide_body(*pp, pb, pass, init);
+  if (threadIdx.x == 0) publish_pass_count(pb, pass);
 }
 
 int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st) {
