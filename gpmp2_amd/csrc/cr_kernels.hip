@@ -119,93 +119,6 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
 #define G2_ASTAMP(k) do {} while (0)
 #endif
 
-// =============================================================================== assemble
-template <int D, bool LIE>
-__global__ __launch_bounds__(64) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
-                                                  const double* __restrict__ traj, int bufsel,
-                                                  double* __restrict__ tiles,
-                                                  const int* __restrict__ active) {
-  constexpr int n = 2 * D;
-  using Asm = Assembler<D, LIE>;
-  const PlanParams& P = *pp;
-  const int N = P.N;
-  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
-  if (active && !active[b]) return;
-  // Dogleg retries (phase 1: same linearization, smaller trust region) need no new factorisation
-  if (P.opt_type == GPMP2MI_OPT_DOGLEG && active && pb.phase[b] != 0) return;
-  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-  extern __shared__ __attribute__((aligned(16))) double asm_smem[];
-  const double* rec = rec_of(pb, pb.which[b], bufsel);
-  const double* gpu = gpu_of(pb, pb.which[b], bufsel);
-  Asm as(P, pb, rec, gpu, b, lane);
-  G2_ASTAMP(0);
-  const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
-  as.stage2(i, slot0, slot1);
-  __syncthreads();
-  G2_ASTAMP(1);
-  const bool odd = (i & 1) != 0;
-  Tile S, Cl, Cr;
-  double err_acc = as.build_tiles(i, slot0, slot1, traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr,
-                                  odd || P.opt_type == GPMP2MI_OPT_DOGLEG);
-  G2_ASTAMP(2);
-  err_acc = wave_sum(err_acc);
-  if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
-  // gradient g_i (the rhs column holds -g_i), kept for the step-control scalars of LM / Dogleg
-  if (c == RHSCOL) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) pb.gvec[((size_t)b * (N + 1) + i) * 16 + g + 4 * k] = -S.r[k];
-  }
-  if (P.opt_type == GPMP2MI_OPT_DOGLEG) {  // un-eliminated blocks for g^T H g (k_ghg)
-    double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * TILE_DBL;
-    tile_store(ht, S, lane);
-    tile_store(ht + TILE_DBL, Cr, lane);
-  }
-  if (P.opt_type == GPMP2MI_OPT_LM) {  // LM damping: sqrt(lambda) I prior rows on every variable
-    const double lam = pb.lambda[b];
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (g + 4 * k == c && c < n) S.r[k] += lam;
-  }
-  if (!odd) {
-    tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
-  } else {
-    // level h = 1 of the cyclic reduction: odd blocks only couple to their (even) neighbours, so
-    // they are eliminated right here, spread over the whole chip instead of one CU per trajectory
-    Tile V;
-#pragma unroll
-    for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
-    G2_ASTAMP(3);
-    const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
-    G2_ASTAMP(4);
-    double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
-    tile_store(f, Cl, lane);
-    tile_store(f + TILE_DBL, Cr, lane);
-    tile_store(f + 2 * TILE_DBL, V, lane);
-    if (!ok && lane == 0) pb.notspd[b] = 1;
-    G2_ASTAMP(5);
-  }
-}
-
-int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
-                    const int* active, hipStream_t st) {
-  const dim3 grid(hp.B * (hp.N + 1)), block(64);
-  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
-  switch (hp.D) {
-#define G2_ASM_CASE(DD) \
-  case DD:                                                                                              \
-    if (hp.lie) k_assemble<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active); \
-    else k_assemble<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active);       \
-    break;
-    G2_ASM_CASE(1) G2_ASM_CASE(2) G2_ASM_CASE(3) G2_ASM_CASE(4) G2_ASM_CASE(5) G2_ASM_CASE(6) G2_ASM_CASE(7)
-#undef G2_ASM_CASE
-    default:
-      set_error("block solver is instantiated for dof <= 7");
-      return GPMP2MI_ERR_UNSUPPORTED;
-  }
-  G2_HIP(hipGetLastError());
-  return GPMP2MI_OK;
-}
-
 // S -= A^T A restricted to real rows (< n) and to the matrix + rhs columns
 template <int n>
 __device__ __forceinline__ void schur_sub(Tile& S, const Tile& A, int lane) {
@@ -223,6 +136,144 @@ __device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane)
 #pragma unroll
   for (int k = 0; k < 4; k++) T.r[k] = ((g + 4 * k) < n && c < n) ? -T.r[k] : 0.0;
   return T;
+}
+
+// =============================================================================== assemble
+// One workgroup = 4 wavefronts = the 4 consecutive blocks 4q .. 4q+3 of one trajectory; wavefront r
+// forms block i = 4q + r.  Levels 1 AND 2 of the cyclic reduction happen here, spread over the whole
+// chip: odd blocks (r = 1, 3) are eliminated as soon as they are formed; block 4q + 2 then absorbs
+// their Schur complements (handed over through LDS), gets its fill-in couplings to 4q and 4q + 4 and is
+// eliminated too.  The per-trajectory solve kernels start at level 4 (cr_forward).
+constexpr int ASM_WAVES = 4;
+template <int D, bool LIE>
+__global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                              const double* __restrict__ traj, int bufsel,
+                                                              double* __restrict__ tiles,
+                                                              const int* __restrict__ active) {
+  constexpr int n = 2 * D;
+  using Asm = Assembler<D, LIE>;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int groups = (N + ASM_WAVES) / ASM_WAVES;  // ceil((N + 1) / 4)
+  const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
+  if (active && !active[b]) return;
+  // Dogleg retries (phase 1: same linearization, smaller trust region) need no new factorisation
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG && active && pb.phase[b] != 0) return;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int i = ASM_WAVES * q + wv;
+  const bool live = i <= N;             // the last group may be partly empty
+  const int ic = live ? i : N;          // idle wavefronts shadow block N up to the barriers
+  extern __shared__ __attribute__((aligned(16))) double asm_smem[];
+  const int slot_dbl = 2 * Asm::slot_doubles(P.I, P.REC, P.GPREC);
+  double* my_smem = asm_smem + (size_t)wv * slot_dbl;
+  double* xch = asm_smem + (size_t)ASM_WAVES * slot_dbl;   // [2 odd blocks][Wl, Wr] tiles for level 2
+  const double* rec = rec_of(pb, pb.which[b], bufsel);
+  const double* gpu = gpu_of(pb, pb.which[b], bufsel);
+  Asm as(P, pb, rec, gpu, b, lane);
+  G2_ASTAMP(0);
+  const typename Asm::Slot slot0 = as.make_slot(my_smem, 0), slot1 = as.make_slot(my_smem, 1);
+  as.stage2(ic, slot0, slot1);
+  __syncthreads();
+  G2_ASTAMP(1);
+  const bool odd = (i & 1) != 0;
+  const bool fuse2 = N >= 2;            // level 2 is fused here unless it is the final level (N < 2)
+  const bool lvl2 = fuse2 && wv == 2 && live;
+  Tile S, Cl, Cr;
+  double err_acc = as.build_tiles(ic, slot0, slot1, traj + ((size_t)b * (N + 1) + ic) * n, S, Cl, Cr,
+                                  odd || P.opt_type == GPMP2MI_OPT_DOGLEG);
+  G2_ASTAMP(2);
+  if (live) {
+    err_acc = wave_sum(err_acc);
+    if (lane == 0) pb.epart[(size_t)b * P.Npad + i] = 0.5 * err_acc;
+    // gradient g_i (the rhs column holds -g_i), kept for the step-control scalars of LM / Dogleg
+    if (c == RHSCOL) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) pb.gvec[((size_t)b * (N + 1) + i) * 16 + g + 4 * k] = -S.r[k];
+    }
+    if (P.opt_type == GPMP2MI_OPT_DOGLEG) {  // un-eliminated blocks for g^T H g (k_ghg)
+      double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * TILE_DBL;
+      tile_store(ht, S, lane);
+      tile_store(ht + TILE_DBL, Cr, lane);
+    }
+    if (P.opt_type == GPMP2MI_OPT_LM) {  // LM damping: sqrt(lambda) I prior rows on every variable
+      const double lam = pb.lambda[b];
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (g + 4 * k == c && c < n) S.r[k] += lam;
+    }
+    if (!odd) {
+      if (!lvl2) tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
+    } else {
+      // level h = 1: odd blocks only couple to their (even) neighbours
+      Tile V;
+#pragma unroll
+      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+      G2_ASTAMP(3);
+      const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
+      G2_ASTAMP(4);
+      double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
+      tile_store(f, Cl, lane);
+      tile_store(f + TILE_DBL, Cr, lane);
+      tile_store(f + 2 * TILE_DBL, V, lane);
+      if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2
+        double* x = xch + (size_t)(wv >> 1) * 2 * TILE_DBL;
+        tile_store(x, Cl, lane);
+        tile_store(x + TILE_DBL, Cr, lane);
+      }
+      if (!ok && lane == 0) pb.notspd[b] = 1;
+      G2_ASTAMP(5);
+    }
+  }
+  if (!fuse2) return;
+  __syncthreads();
+  if (!lvl2) return;
+  // level h = 2, block j = 4q + 2 (an odd multiple of 2): the E task of cr_forward with the
+  // neighbours' factor tiles taken from LDS
+  {
+    const int j = i;
+    const Tile Wr_m = tile_load(xch + TILE_DBL, lane);       // block j - 1: W_r
+    schur_sub<n>(S, Wr_m, lane);
+    const Tile Wl_m = tile_load(xch, lane);                  // block j - 1: W_l
+    Tile C2l = coupling<n>(Wr_m, Wl_m, lane);                // rows j, cols j - 2
+    Tile C2r = tile_zero();
+    if (j + 1 <= N) {
+      const Tile Wl_p = tile_load(xch + 2 * TILE_DBL, lane); // block j + 1: W_l
+      schur_sub<n>(S, Wl_p, lane);
+      if (j + 2 <= N) {
+        const Tile Wr_p = tile_load(xch + 3 * TILE_DBL, lane);
+        C2r = coupling<n>(Wl_p, Wr_p, lane);                 // rows j, cols j + 2
+      }
+    }
+    Tile V;
+#pragma unroll
+    for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+    const bool ok = tile_eliminate3<n>(S, C2l, C2r, V, lane);
+    double* f = pb.fac + ((size_t)b * (N + 1) + j) * 3 * TILE_DBL;
+    tile_store(f, C2l, lane);
+    tile_store(f + TILE_DBL, C2r, lane);
+    tile_store(f + 2 * TILE_DBL, V, lane);
+    if (!ok && lane == 0) pb.notspd[b] = 1;
+  }
+}
+
+int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                    const int* active, hipStream_t st) {
+  const dim3 grid(hp.B * ((hp.N + ASM_WAVES) / ASM_WAVES)), block(64 * ASM_WAVES);
+  const size_t shmem = (ASM_WAVES * 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) + 4 * TILE_DBL) * sizeof(double);
+  switch (hp.D) {
+#define G2_ASM_CASE(DD) \
+  case DD:                                                                                              \
+    if (hp.lie) k_assemble<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active); \
+    else k_assemble<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, pb.tiles, active);       \
+    break;
+    G2_ASM_CASE(1) G2_ASM_CASE(2) G2_ASM_CASE(3) G2_ASM_CASE(4) G2_ASM_CASE(5) G2_ASM_CASE(6) G2_ASM_CASE(7)
+#undef G2_ASM_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
 }
 
 // sum over the 16 lanes of a DPP row, result in every lane of the row
@@ -283,7 +334,11 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  for (int h = 2; h <= hfinal; h <<= 1) {
+  // levels 1 and 2 were done by k_assemble (level 2 only when it is not the final one, N >= 2); the
+  // level-2 updates of the surviving blocks (multiples of 4) were NOT applied there, so they are
+  // absorbed together with the level-4 ones
+  const int h0 = (N >= 2) ? 4 : 2;
+  for (int h = h0; h <= hfinal; h <<= 1) {
     const bool final = (h == hfinal);
     const int hh = h >> 1;
     const int countE = final ? 1 : ((N / h) + 1) / 2;
@@ -293,6 +348,10 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
       Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
       Tile Cl = tile_zero(), Cr = tile_zero();
+      if (h == 4 && h0 == 4) {  // pending level-1 Schur complements of the odd neighbours
+        if (j - 1 >= 0) schur_sub<n>(S, tile_load(fac + (size_t)(j - 1) * 3 * TILE_DBL + TILE_DBL, lane), lane);
+        if (j + 1 <= N) schur_sub<n>(S, tile_load(fac + (size_t)(j + 1) * 3 * TILE_DBL, lane), lane);
+      }
       const int jm = j - hh, jp = j + hh;
       if (jm >= 0) {
         const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
@@ -324,6 +383,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       tile_store(f + 2 * TILE_DBL, V, lane);
     }
     __syncthreads();
+    G2_STAMP(5 + __builtin_ctz(h));   // 6.. : after level h = 2, 4, ...
   }
   return ok;
 }
@@ -349,6 +409,7 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
       if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
     }
     __syncthreads();
+    G2_STAMP(16 + __builtin_ctz(h));  // 16.. : after backward level h
   }
 
 }

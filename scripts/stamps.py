@@ -12,11 +12,13 @@ for _ in range(3): pl.optimize()
 for b in (0, 33):
     out = (C.c_ulonglong * 64)()
     e._ck(e.lib.gpmp2mi_plan_debug_stamps(pl.h.ptr, b, out))
-    t = np.array(list(out), dtype=np.float64)
-    k = int((t > 0).sum())
-    d = np.diff(t[:k])
-    tl = np.array(list(out)[48:56], dtype=np.float64)
-    print('   linearize wave (b, chunk 1): stage_robot/state+interp/sweep1/lookups/sweep2/stores/gp cycles', [int(x) for x in np.diff(tl)])
-    ta = np.array(list(out)[32:40], dtype=np.float64)
+    raw = np.array(list(out), dtype=np.float64)
+    tl = raw[48:56]
+    print('   linearize wave (b, chunk 1): stage+state+interp/-/spheres/stores/gp cycles', [int(x) for x in np.diff(tl[tl > 0])])
+    ta = raw[32:40]
     print('   assemble wave (b, i=1): stage/build/misc/elim/store cycles', [int(x) for x in np.diff(ta[:6])])
-    print(path.split('/')[-1], 'traj', b, 'phases(cycles/100MHz ticks?):', [int(x) for x in d], 'total', int(t[k-1]-t[0]))
+    print('   step kernel: control', int(raw[1] - raw[0]), 'forward', int(raw[2] - raw[1]), 'backward', int(raw[3] - raw[2]), 'retract', int(raw[4] - raw[3]))
+    fw = [raw[1]] + [raw[5 + k] for k in range(1, 9) if raw[5 + k] > 0]
+    print('   forward levels h=2,4,..:', [int(x) for x in np.diff(fw)])
+    bw = [raw[2]] + [raw[16 + k] for k in range(8, -1, -1) if raw[16 + k] > 0]
+    print('   backward levels h=final..1:', [int(x) for x in np.diff(bw)])
