@@ -455,3 +455,15 @@ def test_replanner_fix_state_change_goal_update(engine, oracle):
     pl.optimize()
     ref3 = oracle.batch_optimize(ro, so, p.setting, p.start_conf, p.start_vel, end, p.end_vel, p.init)
     np.testing.assert_allclose(pl.result()["traj"], ref3["traj"], atol=1e-6)
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 33, 64, 65])
+@pytest.mark.parametrize("opt", ["GN", "LM"])
+def test_every_tree_shape_of_the_cyclic_reduction(engine, oracle, N, opt):
+    """trajectory lengths around every power of two: each one exercises a different shape of the
+    elimination tree (levels fused into the assemble kernel, last partly filled group, final level)"""
+    p = problems.wam_restarts(B=3, total_step=N, obs_check_inter=2, opt=opt, sdf="40", max_iter=6)
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    _compare_solves(res, ref, p.setting.max_iter)
