@@ -42,6 +42,8 @@ __device__ __forceinline__ int edt_line_min(const int* __restrict__ line, int st
   return best;
 }
 
+// A line without any finite value stays all-INF (typical for the first pass over a sparse map: most
+// rows contain no obstacle cell); the per-line flag spares its cells the full-length search.
 // pass along the contiguous axis: a block stages `rows` consecutive lines of length len
 __global__ void k_edt_x(int len, size_t nrows, int rows, int* __restrict__ va, int* __restrict__ vb) {
   extern __shared__ int edt_lds[];
@@ -50,11 +52,18 @@ __global__ void k_edt_x(int len, size_t nrows, int rows, int* __restrict__ va, i
   const int nr = (int)min((size_t)rows, nrows - r0);
   const int cnt = nr * len;
   int* g = v + r0 * len;
-  for (int e = threadIdx.x; e < cnt; e += blockDim.x) edt_lds[e] = g[e];
+  int* has = edt_lds + rows * len;  // [rows] line contains a finite value
+  for (int r = threadIdx.x; r < nr; r += blockDim.x) has[r] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
+    const int x = g[e];
+    edt_lds[e] = x;
+    if (x < EDT_INF) has[e / len] = 1;  // every writer stores the same value
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < cnt; e += blockDim.x) {
     const int r = e / len, x = e - r * len;
-    g[e] = edt_line_min(edt_lds + r * len, 1, len, x);
+    if (has[r]) g[e] = edt_line_min(edt_lds + r * len, 1, len, x);
   }
 }
 
@@ -69,9 +78,16 @@ __global__ void k_edt_strided(int len, size_t inner, int* __restrict__ va, int* 
   int* g = v + (size_t)blockIdx.y * len * inner + i0;
   const int w = threadIdx.x % W, grp = threadIdx.x / W, ngrp = blockDim.x / W;
   const bool live = i0 + w < inner;
-  for (int j = grp; j < len; j += ngrp) edt_lds[j * W + w] = live ? g[(size_t)j * inner + w] : EDT_INF;
+  int* has = edt_lds + len * W;  // [W] column contains a finite value
+  if (threadIdx.x < W) has[threadIdx.x] = 0;
   __syncthreads();
-  if (!live) return;
+  for (int j = grp; j < len; j += ngrp) {
+    const int x = live ? g[(size_t)j * inner + w] : EDT_INF;
+    edt_lds[j * W + w] = x;
+    if (x < EDT_INF) has[w] = 1;
+  }
+  __syncthreads();
+  if (!live || !has[w]) return;
   for (int j = grp; j < len; j += ngrp) g[(size_t)j * inner + w] = edt_line_min(edt_lds + w, W, len, j);
 }
 
@@ -97,10 +113,10 @@ int launch_sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double 
     if (len < 2) return GPMP2MI_OK;
     if ((size_t)len * 64 * sizeof(int) <= kLdsBudget) {
       k_edt_strided<64><<<dim3((unsigned)((inner + 63) / 64), (unsigned)outer, 2), dim3(256),
-                          (size_t)len * 64 * sizeof(int), st>>>(len, inner, wa, wb);
+                          ((size_t)len * 64 + 64) * sizeof(int), st>>>(len, inner, wa, wb);
     } else if ((size_t)len * 8 * sizeof(int) <= kLdsBudget) {
       k_edt_strided<8><<<dim3((unsigned)((inner + 7) / 8), (unsigned)outer, 2), dim3(256),
-                         (size_t)len * 8 * sizeof(int), st>>>(len, inner, wa, wb);
+                         ((size_t)len * 8 + 8) * sizeof(int), st>>>(len, inner, wa, wb);
     } else {
       set_error("occupancy grid axis too long for the LDS-staged distance transform (max 4608 cells)");
       return GPMP2MI_ERR_UNSUPPORTED;
@@ -114,7 +130,7 @@ int launch_sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double 
     }
     const size_t nrows = (size_t)ny * nz;
     const int rows = (int)std::max<size_t>(1, std::min<size_t>(nrows, 2048 / nx));
-    k_edt_x<<<dim3((unsigned)((nrows + rows - 1) / rows), 1, 2), dim3(256), (size_t)rows * nx * sizeof(int), st>>>(
+    k_edt_x<<<dim3((unsigned)((nrows + rows - 1) / rows), 1, 2), dim3(256), ((size_t)rows * nx + rows) * sizeof(int), st>>>(
         nx, nrows, rows, wa, wb);
   }
   G2_TRY(strided(ny, (size_t)nx, (size_t)nz));
