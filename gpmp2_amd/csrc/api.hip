@@ -157,7 +157,9 @@ struct KernelTimer {
   hipEvent_t get() {
     if (pool_used == pool.size()) {
       hipEvent_t e;
-      (void)hipEventCreate(&e);
+      // timing only: no system-scope fence when the event fires (the default flushes caches between the
+      // two kernels it separates)
+      (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
       pool.push_back(e);
     }
     return pool[pool_used++];
