@@ -10,6 +10,13 @@ from .robots import (Arm, ArmModel, BodySphere, PointRobot, PointRobotModel, Pos
                      Pose2MobileBaseModel, Pose2MobileVetLin2Arms, Pose2MobileVetLin2ArmsModel,
                      Pose2MobileVetLinArm, Pose2MobileVetLinArmModel, generateArm, generateMobileArm,
                      generatePointRobot, pose3, rot_yaw)
+from .factors import (GaussianPriorWorkspaceOrientationArm, GaussianPriorWorkspacePoseArm,  # noqa: F401
+                      GaussianPriorWorkspacePositionArm, GaussianProcessInterpolatorLinear,
+                      GaussianProcessInterpolatorPose2Vector, GaussianProcessPriorLinear,
+                      GaussianProcessPriorPose2Vector, GoalFactorArm, JointLimitFactorVector,
+                      ObstaclePlanarSDFFactorArm, ObstaclePlanarSDFFactorGPArm, ObstaclePlanarSDFFactorGPPointRobot,
+                      ObstaclePlanarSDFFactorPointRobot, ObstacleSDFFactorArm, ObstacleSDFFactorGPArm,
+                      SelfCollisionArm, VelocityLimitFactorVector)
 from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2MobileArm,  # noqa: F401
                       BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,
