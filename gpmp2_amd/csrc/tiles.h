@@ -25,7 +25,9 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   r = fma(fma(-x, r, 1.0), r, r);
+#ifdef G2_RCP_TWO_NEWTON
   r = fma(fma(-x, r, 1.0), r, r);
+#endif
   return r;
 }
 
