@@ -467,3 +467,44 @@ def test_every_tree_shape_of_the_cyclic_reduction(engine, oracle, N, opt):
     res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
     ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
     _compare_solves(res, ref, p.setting.max_iter)
+
+
+def test_edge_sizes_empty_long_and_many_spheres(engine, oracle):
+    """edge cases: empty batches of evaluations, a single long trajectory (N = 600, beyond one wavefront of
+    blocks per level), the largest sphere model the engine stages (64), a robot entirely outside the field"""
+    import gpmp2_amd as g
+    p = problems.wam_restarts(B=1, total_step=600, obs_check_inter=1, opt="GN", sdf="40", max_iter=4)
+    r, s, ro, so = _handles(engine, oracle, p)
+    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    # delta_t = total_time / 600 makes Q^-1 ~ 12 / delta_t^3 and the normal equations ill-conditioned: two
+    # backward-stable Cholesky orders (cyclic reduction here, natural order in the oracle) then agree to
+    # ~ cond * eps only -- measured 1e-10 at N = 100, 6e-9 at N = 300, 4e-7 at N = 600
+    # (scripts/long_traj_cond.py); the control flow (iterations, status) must still be identical
+    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+    m = ~np.isnan(ref["error_trace"])
+    np.testing.assert_allclose(res["error_trace"][m], ref["error_trace"][m], rtol=1e-5)
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-5)
+    # M = 0 evaluations are a no-op at every factor-level entry point
+    z7 = np.zeros((0, 7))
+    assert engine.obstacle_factor(r, s, 0.2, z7)[0].shape == (0, 16)
+    assert engine.sphere_centers(r, z7)[0].shape == (0, 16, 3)
+    assert engine.forward_kinematics(r, z7)[0].shape == (0, 7, 4, 4)
+    assert engine.gp_prior_factor(7, False, 0.1, z7, z7, z7, z7)[0].shape == (0, 14)
+    assert engine.sdf_query(s, np.zeros((0, 3)))[0].shape == (0,)
+    # 64 body spheres (GPMP2MI_MAX_SPHERES) on a 7-dof arm; one more is rejected
+    wam = g.generateArm("WAMArm")
+    rng = np.random.default_rng(77)
+    sph = [g.BodySphere(int(rng.integers(0, 7)), 0.04, tuple(rng.uniform(-0.1, 0.1, size=3))) for _ in range(64)]
+    big = g.ArmModel(wam.fk_model(), sph)
+    rb, rbo = engine.robot(big), oracle.robot(big)
+    q = rng.uniform(-1.5, 1.5, size=(20, 7))
+    a, b = engine.obstacle_factor(rb, s, 0.2, q), oracle.obstacle_factor(rbo, so, 0.2, q)
+    np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+    np.testing.assert_allclose(a[1], b[1], atol=1e-8)
+    with pytest.raises(g.engine.Gpmp2miError):
+        engine.robot(g.ArmModel(wam.fk_model(), sph + [g.BodySphere(0, 0.04, (0, 0, 0))]))
+    # a robot far outside the field: SDFQueryOutOfRange is swallowed into zero error / zero Jacobian rows
+    far = g.ArmModel(g.Arm(7, wam.fk_model().a, wam.fk_model().alpha, wam.fk_model().d, g.pose3(t=(50.0, 0.0, 0.0))), sph[:8])
+    a, b = engine.obstacle_factor(engine.robot(far), s, 0.2, q), oracle.obstacle_factor(oracle.robot(far), so, 0.2, q)
+    assert not a[0].any() and not a[1].any() and not b[0].any()
