@@ -137,3 +137,25 @@ def test_vetlin_2arms_plan_is_rejected_cleanly(engine, golden):
     with pytest.raises(g.engine.Gpmp2miError) as e:
         engine.plan(r, s, p.setting, 1)
     assert e.value.code == 4                                   # GPMP2MI_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("arm_dof", [1, 4])
+def test_mobile_arm_other_sizes(engine, oracle, arm_dof):
+    """Pose2MobileArm with 1 and 4 arm joints (dof 4 and 7, the widest the block solver takes)"""
+    arm = g.Arm(arm_dof, [0.4] * arm_dof, [0.0, np.pi / 2, 0.0, -np.pi / 2][:arm_dof], [0.1] * arm_dof)
+    fk = g.Pose2MobileArm(arm, g.pose3(g.rot_yaw(0.3), (0.2, 0.0, 0.5)))
+    sph = [g.BodySphere(l, 0.12, (-0.1, 0.0, 0.0)) for l in range(fk.nr_links())] + [g.BodySphere(0, 0.3, (0.0, 0.0, 0.2))]
+    model = g.Pose2MobileArmModel(fk, sph)
+    r, ro = engine.robot(model), oracle.robot(model)
+    q = np.random.default_rng(3).uniform(-2, 2, size=(20, model.dof()))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-11)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-11)
+    p = _tree_problem(model, N=10, inter=2, opt="GN")
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    res = engine.batch_optimize(r, s, p.setting, *args, p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
