@@ -821,6 +821,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.REC = P.NG + D + 1 + ((robot->h.base_dof == 3 && P.I > 0) ? 36 : 0);
   P.Npad = (P.N + 1 + 63) / 64 * 64;
   P.lie = robot->h.base_dof == 3 ? 1 : 0;
+  P.split_back = (P.N >= 8) ? 1 : 0;
   P.GPREC = P.n + 1 + (P.lie ? 18 : 0);
   P.obs_skip_first = o.obs_skip_first_state;
   P.flag_pos_limit = s->flag_pos_limit;
@@ -899,6 +900,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.hgpart, (size_t)B * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
+  G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
+  G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * 16));
   G2_TRY(plan_alloc(p.get(), &pb.xp_n, B));
   G2_TRY(plan_alloc(p.get(), &pb.xp_state, (size_t)B * XP_MAX));
   G2_TRY(plan_alloc(p.get(), &pb.xp_has_vel, (size_t)B * XP_MAX));
@@ -1030,6 +1033,10 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
       G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
       p->timer.begin("gn_step_cr", st);
       G2_TRY(launch_gn_step_cr(P, pb, pass, st));
+      if (P.split_back) {
+        p->timer.begin("finish_step", st);
+        G2_TRY(launch_finish_step(P, pb, pass, st));
+      }
       p->timer.close(st);
       if (pass >= 1) {
         int cnt = 0;

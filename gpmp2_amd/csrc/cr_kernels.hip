@@ -388,14 +388,15 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   return ok;
 }
 
-// Back-substitution down the same tree; leaves x of every block in xs[(N+1)][16] (LDS).
+// Back-substitution down the same tree, levels hfinal .. hmin; leaves x of every block it reaches in
+// xs[(N+1)][16] (LDS).
 template <int n>
-__device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs) {
+__device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs, int hmin = 1) {
   const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  for (int h = hfinal; h >= 1; h >>= 1) {
+  for (int h = hfinal; h >= hmin; h >>= 1) {
     const bool final = (h == hfinal);
     const int count = final ? 1 : ((N / h) + 1) / 2;
     for (int idx = w; idx < count; idx += CR_WAVES) {
@@ -498,6 +499,22 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
     return;
   }
 
+  if (P.split_back) {
+    // the two widest back-substitution levels (75 of the 101 blocks) and the retract run chip-wide in
+    // k_finish_step; this kernel only solves the blocks that are multiples of 4 and hands them over
+    cr_backward<n>(pb, b, N, tid, xs, 4);
+    G2_STAMP(3);
+    double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+    for (int k = tid; k < (N / 4 + 1) * 16; k += blockDim.x) xg[(size_t)(k >> 4) * 64 + (k & 15)] = xs[(k >> 4) * 64 + (k & 15)];
+    G2_STAMP(4);
+    if (tid == 0) {
+      pb.stepped[b] = pass + 1;
+      pb.last_err[b] = pb.cur_err[b];
+      pb.iters[b] += 1;
+      atomicAdd(pb.n_active + pass, 1);
+    }
+    return;
+  }
   cr_backward<n>(pb, b, N, tid, xs);
   G2_STAMP(3);
   // ---- last = cur ; cur = retract(cur, delta)   (Values::retract; Pose2 chart for mobile bases)
@@ -521,6 +538,63 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
                                                                PlanBuffers pb, int pass) {
   gn_step_body<D>(*pp, pb, pass);
   if (threadIdx.x == 0) publish_pass_count(pb, pass);
+}
+
+// Chip-wide tail of a Gauss-Newton pass (split path): one workgroup of 4 wavefronts per (trajectory, blocks
+// 4q .. 4q+3).  Block 4q+2 is back-substituted from x_{4q}, x_{4q+4} (level 2), then the odd blocks from
+// their neighbours (level 1), then every wavefront retracts its own state: last = cur; cur = cur (+) x.
+template <int D>
+__global__ __launch_bounds__(256) void k_finish_step(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int groups = (N + 4) / 4;
+  const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
+  if (pb.stepped[b] != pass + 1) return;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int i = 4 * q + wv;
+  const bool live = i <= N;
+  __shared__ double xl_[4][16];
+  const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  auto solve = [&](int j, int h) {
+    const double* f = fac + (size_t)j * 3 * TILE_DBL;
+    const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
+    const int jl = j - h, jr = j + h;
+    auto xof = [&](int m) { return (m & 3) ? xl_[m & 3][c] : xg[(size_t)m * 16 + c]; };
+    const double xl = (jl >= 0) ? xof(jl) : 0.0;
+    const double xr = (jr <= N) ? xof(jr) : 0.0;
+    const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+    if (g == 0) xl_[j & 3][c] = (c < n) ? x : 0.0;
+  };
+  if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(4 * q) * 16 + lane];
+  if (wv == 2 && live) solve(i, 2);
+  __syncthreads();
+  if ((wv & 1) && live) solve(i, 1);
+  __syncthreads();
+  if (!live || lane >= n) return;
+  const size_t k = ((size_t)b * (N + 1) + i) * n + lane;
+  const double* zs = pb.cur + ((size_t)b * (N + 1) + i) * n;
+  const double zold = zs[lane];
+  const double znew = (lane < D) ? retract_coord(P.lie != 0, lane, zs, xl_[wv]) : zold + xl_[wv][lane];
+  pb.last[k] = zold;
+  __builtin_amdgcn_wave_barrier();  // every lane has read the old state of this block before any lane overwrites it
+  pb.cur[k] = znew;
+}
+
+int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {
+  const dim3 grid(hp.B * ((hp.N + 4) / 4)), block(256);
+  switch (hp.D) {
+#define G2_FIN_CASE(DD) \
+  case DD: k_finish_step<DD><<<grid, block, 0, st>>>(pb.params, pb, pass); break;
+    G2_FIN_CASE(1) G2_FIN_CASE(2) G2_FIN_CASE(3) G2_FIN_CASE(4) G2_FIN_CASE(5) G2_FIN_CASE(6) G2_FIN_CASE(7)
+#undef G2_FIN_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
 }
 
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {

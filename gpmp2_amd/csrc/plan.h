@@ -15,6 +15,7 @@ struct PlanParams {
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
+  int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
   double conf_prior_w, vel_prior_w;    // 1 / sigma^2
   double vdyn_w;                       // 1 / dynamics_sigma^2 or 0
@@ -60,6 +61,8 @@ struct PlanBuffers {
   double* xp_target;       // [B][XP_MAX][2D] conf, vel
   double* xp_info;         // [B][XP_MAX][2][D*D] information matrices (conf, vel)
   int* goal_on;            // [B] 0 after removeGoalConfigAndVel
+  double* xg;              // [B][N+1][16] step of the blocks the solve kernel back-substitutes itself (split path)
+  int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path)
   int* which;              // [B] record buffer (0: rec/gpu, 1: rec2/gpu2) holding the linearization at `cur`
   // per-trajectory scalars
   double* cur_err;         // error at `cur`
@@ -102,6 +105,7 @@ int launch_ghg(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st);
 int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
+int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                         double* err, hipStream_t st);
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,

@@ -257,6 +257,7 @@ __global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) 
   pb.active[b] = 1;
   pb.phase[b] = 0;
   pb.which[b] = 0;
+  pb.stepped[b] = 0;
   for (int k = 0; k < SC_COUNT; k++) pb.scal[(size_t)b * SC_COUNT + k] = 0.0;
   pb.notspd[b] = 0;
   pb.cur_err[b] = pb.prev_err[b] = pb.last_err[b] = pb.final_err[b] = 0.0;
