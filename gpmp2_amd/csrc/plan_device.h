@@ -11,11 +11,12 @@ namespace g2 {
 // prior + limit + vehicle-dynamics error of one trajectory (0.5 * whitened squared residuals),
 // wave-reduced.  PriorFactor (planner/BatchTrajOptimizer-inl.h:41-48), JointLimitFactorVector,
 // VelocityLimitFactorVector (:50-59), VehicleDynamicsFactor (dynamics/VehicleDynamics.h:19-27).
-__device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuffers& pb, int b,
-                                             const double* __restrict__ tr, int lane) {
+// this thread's share when `nthr` threads split the entries (not yet reduced)
+__device__ __forceinline__ double misc_error_partial(const PlanParams& P, const PlanBuffers& pb, int b,
+                                                     const double* __restrict__ tr, int tid, int nthr) {
   const int D = P.D, n = P.n, N = P.N;
   double acc = 0.0;
-  for (int idx = lane; idx < (N + 1) * n; idx += 64) {
+  for (int idx = tid; idx < (N + 1) * n; idx += nthr) {
     const int i = idx / n, rho = idx - i * n;
     const int a = rho >= D, k = rho - a * D;
     const double z = tr[idx];
@@ -59,7 +60,11 @@ __device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuff
     }
     if (a && k == 1 && P.vdyn_w > 0.0) acc += P.vdyn_w * z * z;
   }
-  return wave_sum(acc);
+  return acc;
+}
+__device__ __forceinline__ double misc_error(const PlanParams& P, const PlanBuffers& pb, int b,
+                                             const double* __restrict__ tr, int lane) {
+  return wave_sum(misc_error_partial(P, pb, b, tr, lane, 64));
 }
 
 // total graph error of trajectory b from its point records: 0.5 * (sum e_p + sum gp energy + misc)
@@ -73,6 +78,19 @@ __device__ __forceinline__ double total_error(const PlanParams& P, const PlanBuf
   const double* gb = gpu + ((size_t)b * P.GPREC + P.n) * P.Npad;
   for (int i = 1 + lane; i <= P.N; i += 64) acc += gb[i];
   return 0.5 * (wave_sum(acc) + misc_error(P, pb, b, tr, lane));
+}
+
+// the same with the work split over the `nthr` threads of a workgroup: this thread's share of
+// sum e_p + sum gp energy + misc (the caller reduces and halves)
+__device__ __forceinline__ double total_error_partial(const PlanParams& P, const PlanBuffers& pb, int b,
+                                                      const double* __restrict__ tr, const double* __restrict__ rec,
+                                                      const double* __restrict__ gpu, int tid, int nthr) {
+  const double* eb = rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+  double acc = 0.0;
+  for (int p = tid; p < P.P; p += nthr) acc += eb[p];
+  const double* gb = gpu + ((size_t)b * P.GPREC + P.n) * P.Npad;
+  for (int i = 1 + tid; i <= P.N; i += nthr) acc += gb[i];
+  return acc + misc_error_partial(P, pb, b, tr, tid, nthr);
 }
 
 __device__ __forceinline__ bool check_convergence(double rel, double abs_, double err_tol, double cur,

@@ -282,7 +282,12 @@ int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t s
 // followed by the do/while of gpmp2::optimize (checkConvergence, max_iter, no-increase rollback).
 // GTSAM semantics restated from upstream.
 __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffers& pb, int pass, int init) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+  // 4 wavefronts: all of them sum the graph error of the point in question (fixed-order block reduction),
+  // the first thread takes the decision, all four wavefronts then move the trajectories
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const bool w0 = tid < 64;
+  __shared__ int dec[2];
+  __shared__ double red[4];
   if (!pb.active[b]) return;
   const int N = P.N, n = P.n;
   const size_t tsz = (size_t)(N + 1) * n;
@@ -296,8 +301,18 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
   // action: 0 keep iterating, 1 finish with cur, 2 finish with last; accept: copy trial -> cur
   int action = 0, accept = 0;
 
-  if (init) {
-    const double err = total_error(P, pb, b, cur, rec_of(pb, wh, 0), gpu_of(pb, wh, 0), lane);
+  const bool failed = !init && pb.notspd[b] != 0;
+  double err_sum = 0.0;
+  if (!failed) {
+    const double part = init ? total_error_partial(P, pb, b, cur, rec_of(pb, wh, 0), gpu_of(pb, wh, 0), tid, blockDim.x)
+                             : total_error_partial(P, pb, b, trial, rec_of(pb, wh, 1), gpu_of(pb, wh, 1), tid, blockDim.x);
+    const double ws = wave_sum(part);
+    if (lane == 0) red[tid >> 6] = ws;
+  }
+  __syncthreads();
+  if (!failed) err_sum = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+  if (w0 && init) {
+    const double err = err_sum;
     if (lane == 0) {
       pb.cur_err[b] = pb.prev_err[b] = err;
       tr[0] = err;
@@ -305,10 +320,8 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
       else if (P.fixed_iters == 0 && P.max_iter <= 0) { action = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; }
       if (action) pb.final_err[b] = err;
     }
-  } else {
-    const bool failed = pb.notspd[b] != 0;
-    double new_err = 0.0;
-    if (!failed) new_err = total_error(P, pb, b, trial, rec_of(pb, wh, 1), gpu_of(pb, wh, 1), lane);
+  } else if (w0) {
+    const double new_err = err_sum;
     if (lane == 0) {
       pb.notspd[b] = 0;
       const double cur_err = pb.cur_err[b];
@@ -387,37 +400,42 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
       }
     }
   }
-  action = __shfl(action, 0, 64);
-  accept = __shfl(accept, 0, 64);
+  if (tid == 0) {
+    dec[0] = action;
+    dec[1] = accept;
+  }
+  __syncthreads();
+  action = dec[0];
+  accept = dec[1];
   if (accept) {
     if (action == 2) {
       // rollback: the result is the pre-step `cur`; nothing else reads cur afterwards
-      for (size_t k = lane; k < tsz; k += 64) result[k] = cur[k];
+      for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
     } else {
-      for (size_t k = lane; k < tsz; k += 64) {
+      for (size_t k = tid; k < tsz; k += blockDim.x) {
         last[k] = cur[k];
         cur[k] = trial[k];
       }
-      if (lane == 0) pb.which[b] = wh ^ 1;  // the trial linearization is now the one at cur
+      if (tid == 0) pb.which[b] = wh ^ 1;  // the trial linearization is now the one at cur
     }
   }
   if (action == 1) {
-    for (size_t k = lane; k < tsz; k += 64) result[k] = cur[k];
+    for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
   } else if (action == 2 && !accept) {
-    for (size_t k = lane; k < tsz; k += 64) result[k] = last[k];
+    for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = last[k];
   }
-  if (lane == 0) {
+  if (tid == 0) {
     if (action != 0) pb.active[b] = 0;
     else atomicAdd(pb.n_active + pass, 1);
   }
 }
-__global__ __launch_bounds__(64) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
+__global__ __launch_bounds__(256) void k_decide(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass, int init) {
   decide_body(*pp, pb, pass, init);
   if (threadIdx.x == 0) publish_pass_count(pb, pass);
 }
 
 int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st) {
-  k_decide<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, pass, init ? 1 : 0);
+  k_decide<<<dim3(hp.B), dim3(256), 0, st>>>(pb.params, pb, pass, init ? 1 : 0);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
