@@ -6,7 +6,9 @@
 //
 // Exact Euclidean distance transform in integer arithmetic: squared distances are int32, the
 // transform is separable, and every axis pass is   out[i] = min_j in[j] + (i - j)^2   with the
-// line staged in LDS and an outward search that stops as soon as k^2 >= best.  The two target
+// line staged in LDS: the contiguous axis by an outward search that stops as soon as k^2 >= best
+// (lines without any finite value are skipped), the strided axes by a linear-time lower-envelope
+// scan (k_edt_strided_scan; the outward-search form remains as the fallback for very long axes).  The two target
 // sets (obstacle cells, free cells) are two int32 volumes processed by the same launches
 // (blockIdx.z).  HBM-bound integer work: 3 passes x 2 volumes x (4 B read + 4 B write) per cell.
 #include <hip/hip_runtime.h>
@@ -91,6 +93,58 @@ __global__ void k_edt_strided(int len, size_t inner, int* __restrict__ va, int* 
   for (int j = grp; j < len; j += ngrp) g[(size_t)j * inner + w] = edt_line_min(edt_lds + w, W, len, j);
 }
 
+// Linear-time form of the strided pass (Meijster, Roerdink & Hesselink 2000: lower envelope of the
+// parabolas x -> (x - i)^2 + g[i]) in exact integer arithmetic: the same minimum as edt_line_min in
+// O(len) per line instead of O(len * distance).  The [len][W] tile and the envelope stack
+// (s | t << 16 per entry) live in LDS; W threads each scan one line, all threads of the block stage the
+// tile (coalesced along the inner axis); results go straight back to global memory, W consecutive
+// values per store.  Needs len < 32768.
+template <int W>
+__global__ void k_edt_strided_scan(int len, size_t inner, int* __restrict__ va, int* __restrict__ vb) {
+  extern __shared__ int edt_lds[];
+  int* gl = edt_lds;                      // [len][W] input values
+  int* stk = edt_lds + (size_t)len * W;   // [len][W] envelope stack
+  int* v = blockIdx.z ? vb : va;
+  const size_t i0 = (size_t)blockIdx.x * W;
+  int* g = v + (size_t)blockIdx.y * len * inner + i0;
+  const int w = threadIdx.x % W, grp = threadIdx.x / W, ngrp = blockDim.x / W;
+  const bool live = i0 + w < inner;
+  for (int j = grp; j < len; j += ngrp) gl[j * W + w] = live ? g[(size_t)j * inner + w] : EDT_INF;
+  __syncthreads();
+  if (threadIdx.x >= W || !live) return;
+  auto G = [&](int i) { return gl[i * W + w]; };
+  auto F = [&](int x, int i) { return (long long)(x - i) * (x - i) + G(i); };
+  int q = -1;
+  for (int u = 0; u < len; u++) {
+    if (G(u) >= EDT_INF) continue;  // an empty cell contributes no parabola
+    while (q >= 0) {
+      const int e = stk[q * W + w], sq = e & 0xffff, tq = e >> 16;
+      if (F(tq, sq) > F(tq, u)) q--;
+      else break;
+    }
+    if (q < 0) {
+      q = 0;
+      stk[w] = u;  // s = u, valid from t = 0
+    } else {
+      const int sq = stk[q * W + w] & 0xffff;
+      // first x at which the parabola of u lies below the one of sq (u > sq; non-negative after the pops)
+      const long long num = (long long)u * u - (long long)sq * sq + G(u) - G(sq);
+      const long long wpos = 1 + num / (2LL * (u - sq));
+      if (wpos < len) {
+        q++;
+        stk[q * W + w] = u | ((int)wpos << 16);
+      }
+    }
+  }
+  if (q < 0) return;  // no finite value on this line: it stays all-INF
+  for (int u = len - 1; u >= 0; u--) {
+    const int e = stk[q * W + w], sq = e & 0xffff, tq = e >> 16;
+    const long long val = F(u, sq);
+    g[(size_t)u * inner + w] = val < EDT_INF ? (int)val : EDT_INF;
+    if (u == tq) q--;
+  }
+}
+
 // field = (map_dist - inv_map_dist) * cell_size; a volume without obstacles (or without free
 // space) becomes the constant 1000 (signedDistanceField3D.m:30-33)
 __global__ void k_edt_finish(size_t n, const int* __restrict__ a, const int* __restrict__ b, double cell,
@@ -111,7 +165,10 @@ int launch_sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double 
   constexpr size_t kLdsBudget = 144 * 1024;
   auto strided = [&](int len, size_t inner, size_t outer) -> int {
     if (len < 2) return GPMP2MI_OK;
-    if ((size_t)len * 64 * sizeof(int) <= kLdsBudget) {
+    if (len < 32768 && (size_t)len * 32 * 2 * sizeof(int) <= kLdsBudget) {  // linear-time scan, 32 lines per block
+      k_edt_strided_scan<32><<<dim3((unsigned)((inner + 31) / 32), (unsigned)outer, 2), dim3(256),
+                               (size_t)len * 32 * 2 * sizeof(int), st>>>(len, inner, wa, wb);
+    } else if ((size_t)len * 64 * sizeof(int) <= kLdsBudget) {
       k_edt_strided<64><<<dim3((unsigned)((inner + 63) / 64), (unsigned)outer, 2), dim3(256),
                           ((size_t)len * 64 + 64) * sizeof(int), st>>>(len, inner, wa, wb);
     } else if ((size_t)len * 8 * sizeof(int) <= kLdsBudget) {
