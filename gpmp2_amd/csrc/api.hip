@@ -788,12 +788,13 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->dof == D, GPMP2MI_ERR_INVALID, "[TrajOptimizerSetting] dof does not match the robot");
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
-  G2_CHECK(2 * D <= 15, GPMP2MI_ERR_UNSUPPORTED, "block solver is instantiated for dof <= 7");
+  G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 11");
+  const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: dense block path
   {
-    // k_assemble stages an interval with at most 10 loads per lane (assembler.h NLD)
+    // the assembler stages an interval with at most NLD loads per lane (assembler.h: 10, 16 on the wide path)
     const int nd = D * (D + 1) / 2 + D + 1 + ((robot->h.base_dof == 3 && s->obs_check_inter > 0) ? 36 : 0);
     const int gpr = 2 * D + 1 + (robot->h.base_dof == 3 ? 18 : 0);
-    G2_CHECK((s->obs_check_inter + 1) * nd + gpr <= 640, GPMP2MI_ERR_UNSUPPORTED,
+    G2_CHECK((s->obs_check_inter + 1) * nd + gpr <= 64 * (wide ? 16 : 10), GPMP2MI_ERR_UNSUPPORTED,
              "obs_check_inter too large for the staged assembly");
   }
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
@@ -821,7 +822,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.REC = P.NG + D + 1 + ((robot->h.base_dof == 3 && P.I > 0) ? 36 : 0);
   P.Npad = (P.N + 1 + 63) / 64 * 64;
   P.lie = robot->h.base_dof == 3 ? 1 : 0;
-  P.split_back = (P.N >= 8) ? 1 : 0;
+  P.wide = wide ? 1 : 0;
+  P.split_back = (P.N >= 8 && !wide) ? 1 : 0;
   P.GPREC = P.n + 1 + (P.lie ? 18 : 0);
   P.obs_skip_first = o.obs_skip_first_state;
   P.flag_pos_limit = s->flag_pos_limit;
@@ -902,6 +904,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
   G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * 16));
+  if (wide) {
+    G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wHo, (size_t)B * P.N * P.n * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wg, (size_t)B * (P.N + 1) * P.n));
+  }
   G2_TRY(plan_alloc(p.get(), &pb.xp_n, B));
   G2_TRY(plan_alloc(p.get(), &pb.xp_state, (size_t)B * XP_MAX));
   G2_TRY(plan_alloc(p.get(), &pb.xp_has_vel, (size_t)B * XP_MAX));
@@ -1020,7 +1027,7 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
   for (int k = 0; k < p->n_active_len; k++) p->h_flags[k] = -1;  // the previous run has drained (stream sync below)
   G2_TRY(launch_plan_reset(P, pb, st));
   const int iter_cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
-  if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn) {
+  if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn && !P.wide) {
     // ---- Gauss-Newton fast path: 3 launches per pass, step control fused into the solve kernel.
     // Software-pipelined driver: pass k+1 is enqueued before the host looks at the active count of
     // pass k, so the GPU never waits for the host.  When pass k turns out to have finished every
@@ -1055,14 +1062,22 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
     G2_TRY(launch_decide(P, pb, 0, true, st));
     p->timer.close(st);
     for (int pass = 1; pass < max_pass; pass++) {
-      p->timer.begin("assemble", st);
-      G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
-      if (P.opt_type == GPMP2MI_OPT_DOGLEG) {
-        p->timer.begin("ghg", st);
-        G2_TRY(launch_ghg(P, pb, st));
+      if (P.wide) {
+        // blocks wider than one tile (8 <= dof <= 11): dense normal equations + dense block Cholesky
+        p->timer.begin("export_dense", st);
+        G2_TRY(launch_export_normal_eq(P, pb, pb.cur, 0, pb.wHd, pb.wHo, pb.wg, st, pb.active));
+        p->timer.begin("solve_dense", st);
+        G2_TRY(launch_solve_dense(P, pb, st));
+      } else {
+        p->timer.begin("assemble", st);
+        G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+        if (P.opt_type == GPMP2MI_OPT_DOGLEG) {
+          p->timer.begin("ghg", st);
+          G2_TRY(launch_ghg(P, pb, st));
+        }
+        p->timer.begin("solve_step", st);
+        G2_TRY(launch_solve_step(P, pb, st));
       }
-      p->timer.begin("solve_step", st);
-      G2_TRY(launch_solve_step(P, pb, st));
       p->timer.begin("linearize", st);
       G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.trial, 1, pb.active, st));
       p->timer.begin("decide", st);

@@ -42,15 +42,19 @@ struct Assembler {
   const PlanBuffers& pb;
   const double* rec;
   const double* gpu;
-  int b, lane, c, g;
+  int b, lane, c, g;   // c / g: this lane's global column / first global row (tile offsets included)
+  int rhscol;          // column that carries the right-hand side (-g_i)
   // per-lane static decode of its 4 rows
   int tri[4];
   bool valid[4];   // rho < n && c < n
   int a_row[4], k_row[4], a_col, k_col;
 
+  // row0 / col0: offset of the 16x16 tile inside a wider block (blocks with 2 dof > 15 are exported as
+  // 2x2 tiles by k_export_normal_eq); rhscol_: global column of the right-hand side
   __device__ Assembler(const PlanParams& P_, const PlanBuffers& pb_, const double* rec_, const double* gpu_,
-                       int b_, int lane_)
-      : P(P_), pb(pb_), rec(rec_), gpu(gpu_), b(b_), lane(lane_), c(lane_ & 15), g(lane_ >> 4) {
+                       int b_, int lane_, int row0 = 0, int col0 = 0, int rhscol_ = RHSCOL)
+      : P(P_), pb(pb_), rec(rec_), gpu(gpu_), b(b_), lane(lane_), c(col0 + (lane_ & 15)), g(row0 + (lane_ >> 4)),
+        rhscol(rhscol_) {
     a_col = c >= D;
     k_col = c - a_col * D;
 #pragma unroll
@@ -68,7 +72,7 @@ struct Assembler {
   // only the unary point of state 0, intervals beyond N read as zeros).  All loads of both intervals
   // are issued before the first LDS store so the wavefront pays one memory latency, not one per
   // 64 values; NLD bounds the per-lane load count (checked on the host).
-  static constexpr int NLD = 10;
+  static constexpr int NLD = (D <= 7) ? 10 : 16;
   __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1) const {
     const int I = P.I;
     const double* rb = rec + (size_t)b * P.REC * P.Ppad;
@@ -271,7 +275,7 @@ struct Assembler {
     for (int k = 0; k < 4; k++) {
       const int rho = g + 4 * k;
       if (rho >= n) continue;
-      const bool on_diag = (c == rho), on_rhs = (c == RHSCOL);
+      const bool on_diag = (c == rho), on_rhs = (c == rhscol);
       if (!on_diag && !on_rhs) continue;
       const int ar = a_row[k], kr = k_row[k];
       double dd = 0.0, gg = 0.0, ee = 0.0;

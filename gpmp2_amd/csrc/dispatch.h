@@ -27,18 +27,26 @@
     G2_CASE_(GPMP2MI_ROBOT_ARM, 5, kind, ad, STMT)                                    \
     G2_CASE_(GPMP2MI_ROBOT_ARM, 6, kind, ad, STMT)                                    \
     G2_CASE_(GPMP2MI_ROBOT_ARM, 7, kind, ad, STMT)                                    \
+    G2_CASE_(GPMP2MI_ROBOT_ARM, 8, kind, ad, STMT)                                    \
     G2_CASE_(GPMP2MI_ROBOT_POINT, 0, kind, ad, STMT)                                  \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_BASE, 0, kind, ad, STMT)                      \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 1, kind, ad, STMT)                       \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 2, kind, ad, STMT)                       \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 3, kind, ad, STMT)                       \
     G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 4, kind, ad, STMT)                       \
+    G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 5, kind, ad, STMT)                       \
+    G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 6, kind, ad, STMT)                       \
+    G2_CASE_(GPMP2MI_ROBOT_POSE2_MOBILE_ARM, 7, kind, ad, STMT)                       \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 1, 1, kind, ad, ad2, STMT)            \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 2, 2, kind, ad, ad2, STMT)            \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 3, 3, kind, ad, ad2, STMT)            \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_2ARMS, 4, 4, kind, ad, ad2, STMT)            \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 1, 0, kind, ad, ad2, STMT)       \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 2, 0, kind, ad, ad2, STMT)       \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 3, 0, kind, ad, ad2, STMT)       \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 7, 0, kind, ad, ad2, STMT)       \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 2, 2, kind, ad, ad2, STMT)     \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 3, 3, kind, ad, ad2, STMT)     \
     if (!done_) {                                                                     \
       g2::set_error("robot kind / dof combination is not instantiated");              \
       return GPMP2MI_ERR_UNSUPPORTED;                                                 \

@@ -15,6 +15,7 @@ struct PlanParams {
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
+  int wide;                            // 2 dof > 15: dense block path (k_export_normal_eq + k_solve_dense)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
   double conf_prior_w, vel_prior_w;    // 1 / sigma^2
@@ -61,6 +62,10 @@ struct PlanBuffers {
   double* xp_target;       // [B][XP_MAX][2D] conf, vel
   double* xp_info;         // [B][XP_MAX][2][D*D] information matrices (conf, vel)
   int* goal_on;            // [B] 0 after removeGoalConfigAndVel
+  // dense block-tridiagonal system and its factors (wide path only; n = 2 dof)
+  double* wHd;             // [B][N+1][n][n]   diagonal blocks, then their upper Cholesky factors R_i
+  double* wHo;             // [B][N][n][n]     block (i+1, i), then W_i = R_i^-T H_{i,i+1}
+  double* wg;              // [B][N+1][n]      gradient, then y_i
   double* xg;              // [B][N+1][16] step of the blocks the solve kernel back-substitutes itself (split path)
   int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path)
   int* which;              // [B] record buffer (0: rec/gpu, 1: rec2/gpu2) holding the linearization at `cur`
@@ -106,10 +111,11 @@ int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool in
 int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
+int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                         double* err, hipStream_t st);
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
-                            double* Hdiag, double* Hoff, double* g, hipStream_t st);
+                            double* Hdiag, double* Hoff, double* g, hipStream_t st, const int* active = nullptr);
 int launch_block_tridiag_solve(int B, int nblk, int n, const double* Hd, const double* Ho,
                                const double* b, double* x, int* ok, double* scratch, hipStream_t st);
 

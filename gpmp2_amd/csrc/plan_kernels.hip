@@ -445,46 +445,58 @@ template <int D, bool LIE>
 __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                           const double* __restrict__ traj, int bufsel,
                                                           double* __restrict__ Hd, double* __restrict__ Ho,
-                                                          double* __restrict__ gout) {
+                                                          double* __restrict__ gout, const int* __restrict__ active) {
   constexpr int n = 2 * D;
   using Asm = Assembler<D, LIE>;
   const PlanParams& P = *pp;
   const int N = P.N;
   const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  // optimizer use (wide path): finished trajectories and Dogleg retries keep their last system
+  if (active && (!active[b] || (P.opt_type == GPMP2MI_OPT_DOGLEG && pb.phase[b] != 0))) return;
   const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
   extern __shared__ __attribute__((aligned(16))) double asm_smem[];
   Asm as(P, pb, rec_of(pb, pb.which[b], bufsel), gpu_of(pb, pb.which[b], bufsel), b, lane);
   const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
   as.stage2(i, slot0, slot1);
   __syncthreads();
-  Tile S, Cl, Cr;
-  as.build_tiles(i, slot0, slot1, traj + ((size_t)b * (N + 1) + i) * n, S, Cl, Cr, true);
+  // blocks wider than one tile (2 dof > 15) are walked as 2x2 tiles; the right-hand side rides in the last
+  // column of the tile grid
+  constexpr int T = (n <= 15) ? 1 : 2, RC = 16 * T - 1;
+  const double* zi = traj + ((size_t)b * (N + 1) + i) * n;
+  for (int ti = 0; ti < T; ti++)
+    for (int tj = 0; tj < T; tj++) {
+      Asm at(P, pb, rec_of(pb, pb.which[b], bufsel), gpu_of(pb, pb.which[b], bufsel), b, lane, 16 * ti, 16 * tj, RC);
+      Tile S, Cl, Cr;
+      at.build_tiles(i, slot0, slot1, zi, S, Cl, Cr, true);
+      const int cc = 16 * tj + c;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int rho = g + 4 * k;
-    if (rho < n && c < n) {
-      if (Hd) Hd[(((size_t)b * (N + 1) + i) * n + rho) * n + c] = S.r[k];
-      // the ABI exports block (i+1, i) = H_{i,i+1}^T; also check it against the left coupling of i+1
-      if (Ho && i < N) Ho[(((size_t)b * N + i) * n + c) * n + rho] = Cr.r[k];
+      for (int k = 0; k < 4; k++) {
+        const int rho = 16 * ti + g + 4 * k;
+        if (rho < n && cc < n) {
+          if (Hd) Hd[(((size_t)b * (N + 1) + i) * n + rho) * n + cc] = S.r[k];
+          // the ABI exports block (i+1, i) = H_{i,i+1}^T
+          if (Ho && i < N) Ho[(((size_t)b * N + i) * n + cc) * n + rho] = Cr.r[k];
+        }
+        if (rho < n && cc == RC && gout) gout[((size_t)b * (N + 1) + i) * n + rho] = -S.r[k];
+      }
     }
-    if (rho < n && c == RHSCOL && gout) gout[((size_t)b * (N + 1) + i) * n + rho] = -S.r[k];
-  }
 }
 
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
-                            double* Hd, double* Ho, double* g, hipStream_t st) {
+                            double* Hd, double* Ho, double* g, hipStream_t st, const int* active) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
   const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
   switch (hp.D) {
 #define G2_EXP_CASE(DD) \
   case DD:                                                                                          \
-    if (hp.lie) k_export_normal_eq<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g); \
-    else k_export_normal_eq<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g);       \
+    if (hp.lie) k_export_normal_eq<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g, active); \
+    else k_export_normal_eq<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g, active);       \
     break;
     G2_EXP_CASE(1) G2_EXP_CASE(2) G2_EXP_CASE(3) G2_EXP_CASE(4) G2_EXP_CASE(5) G2_EXP_CASE(6) G2_EXP_CASE(7)
+    G2_EXP_CASE(8) G2_EXP_CASE(9) G2_EXP_CASE(10) G2_EXP_CASE(11)
 #undef G2_EXP_CASE
     default:
-      set_error("block solver is instantiated for dof <= 7");
+      set_error("dof > 11");
       return GPMP2MI_ERR_UNSUPPORTED;
   }
   G2_HIP(hipGetLastError());

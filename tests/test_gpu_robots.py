@@ -129,14 +129,17 @@ def test_tree_robot_plans(engine, oracle, golden, key, opt):
     np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
 
 
-def test_vetlin_2arms_plan_is_rejected_cleanly(engine, golden):
-    """dof 8 > 7: factor level works (above), the block solver does not have tiles for it yet"""
+def test_vetlin_2arms_plans_through_the_dense_path(engine, oracle, golden):
+    """dof 8 > 7: blocks of 16 do not fit one tile, the plan runs on the dense block path"""
     model = tree_robot_from_golden(golden["pose2_mobile_vetlin_2arms"], "pose2_mobile_vetlin_2arms")
     p = _tree_problem(model)
     r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
-    with pytest.raises(g.engine.Gpmp2miError) as e:
-        engine.plan(r, s, p.setting, 1)
-    assert e.value.code == 4                                   # GPMP2MI_ERR_UNSUPPORTED
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    res = engine.batch_optimize(r, s, p.setting, *args, p.init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
 
 
 @pytest.mark.parametrize("arm_dof", [1, 4])
@@ -159,3 +162,61 @@ def test_mobile_arm_other_sizes(engine, oracle, arm_dof):
     ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
     assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
     np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+# ------------------------------------------------------------------ 8 <= dof <= 11: the dense block path
+def _wide_models():
+    wam = g.generateArm("WAMArm")
+    arm7 = wam.fk_model()
+    sph = wam.spheres
+    mob = g.Pose2MobileArm(g.Arm(7, arm7.a, arm7.alpha, arm7.d), g.pose3(g.rot_yaw(0.2), (0.1, 0.0, 0.4)))
+    lift = g.Pose2MobileVetLinArm(g.Arm(7, arm7.a, arm7.alpha, arm7.d), g.pose3(t=(0.0, 0.0, 0.3)), g.pose3(g.rot_yaw(-0.3), (0.2, 0.0, 0.2)))
+    a3 = g.Arm(3, [0.5, 0.4, 0.3], [0.0, np.pi / 2, 0.0], [0.1, 0.0, 0.05])
+    two = g.Pose2Mobile2Arms(a3, a3, g.pose3(g.rot_yaw(0.7), (0.3, 0.2, 0.5)), g.pose3(g.rot_yaw(-0.7), (0.3, -0.2, 0.5)))
+    arm8 = g.Arm(8, [0.3] * 8, [0.0, np.pi / 2, 0.0, -np.pi / 2, 0.0, np.pi / 2, 0.0, 0.0], [0.1] * 8)
+
+    def shift(spheres, k):
+        return [g.BodySphere(s.link_id + k, s.radius, s.center) for s in spheres]
+
+    def simple(fk):
+        return [g.BodySphere(l, 0.15, (-0.05, 0.0, 0.0)) for l in range(fk.nr_links())]
+
+    return {
+        "arm8 (dof 8)": g.ArmModel(arm8, simple(arm8)),
+        "2arms 3+3 (dof 9)": g.RobotModel(two, simple(two)) if hasattr(g, "RobotModel") else g.ArmModel(two, simple(two)),
+        "mobile WAM (dof 10)": g.ArmModel(mob, [g.BodySphere(0, 0.3, (0, 0, 0.2))] + shift(sph, 1)),
+        "lift WAM (dof 11)": g.ArmModel(lift, [g.BodySphere(0, 0.3, (0, 0, 0.2)), g.BodySphere(1, 0.2, (0, 0, 0))] + shift(sph, 2)),
+    }
+
+
+@pytest.mark.parametrize("name", ["arm8 (dof 8)", "2arms 3+3 (dof 9)", "mobile WAM (dof 10)", "lift WAM (dof 11)"])
+def test_wide_robot_linearize_and_plans(engine, oracle, name):
+    """robots whose blocks exceed one 16x16 tile: dense normal equations (2x2 tiles per block) and the
+    dense block-Cholesky trial-step path, GN / LM / Dogleg, against the oracle"""
+    model = _wide_models()[name]
+    D = model.dof()
+    p = _tree_problem(model, N=10, inter=2, opt="GN") if model.kind >= 2 else None
+    if p is None:                                              # fixed-base arm: joint-space endpoints
+        p = _tree_problem(model, N=10, inter=2, opt="GN")
+        p.start_conf[0, :] = 0.1
+        p.end_conf[0, :] = np.linspace(0.3, 0.9, D)
+        for i in range(11):
+            p.init[0, i, :D] = p.start_conf[0] * (10 - i) / 10 + p.end_conf[0] * i / 10
+        p.init[0, :, D:] = (p.end_conf[0] - p.start_conf[0])[None, :] / 3.0
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    rng = np.random.default_rng(29)
+    traj = p.init + 0.05 * rng.normal(size=p.init.shape)
+    a = engine.linearize(r, s, p.setting, *args, traj)
+    b = oracle.linearize(ro, so, p.setting, *args, traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    for opt in ("GN", "LM", "DOGLEG"):
+        {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM, "DOGLEG": p.setting.setDogleg}[opt]()
+        res = engine.batch_optimize(r, s, p.setting, *args, p.init)
+        ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+        assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
+        np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
+        np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
