@@ -52,6 +52,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_solve_dense(const PlanParams*
   int* flags = reinterpret_cast<int*>(red + DENSE_WAVES);
   const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
   const bool resolve = !(dogleg && pb.phase[b] != 0);
+  const int ty = tid >> 4, tx = tid & 15;
   if (tid == 0) flags[0] = 0;
   __syncthreads();
   if (resolve) {
@@ -72,77 +73,77 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_solve_dense(const PlanParams*
     const double lam = (P.opt_type == GPMP2MI_OPT_LM) ? pb.lambda[b] : 0.0;
     // ---- forward: block Cholesky in natural order
     for (int i = 0; i <= N; i++) {
-      for (int e = tid; e < n * AW; e += DENSE_THREADS) {
-        const int r = e / AW, c = e - r * AW;
-        double v;
-        if (c < n) {
-          v = Hd[((size_t)i * n + r) * n + c] + ((r == c) ? lam : 0.0);
-          if (i > 0) {  // Schur complement of the previous block
-            double s = 0.0;
-            for (int k = 0; k < n; k++) s = fma(W[k * n + r], W[k * n + c], s);
-            v -= s;
+      for (int r = ty; r < n; r += 16)
+        for (int c = tx; c < AW; c += 16) {
+          double v;
+          if (c < n) {
+            v = Hd[((size_t)i * n + r) * n + c] + ((r == c) ? lam : 0.0);
+            if (i > 0) {  // Schur complement of the previous block
+              double s = 0.0;
+              for (int k = 0; k < n; k++) s = fma(W[k * n + r], W[k * n + c], s);
+              v -= s;
+            }
+          } else if (c == n) {
+            v = -gv[(size_t)i * n + r];
+            if (i > 0) {
+              double s = 0.0;
+              for (int k = 0; k < n; k++) s = fma(W[k * n + r], xs[(size_t)(i - 1) * n + k], s);
+              v -= s;
+            }
+          } else {
+            v = (i < N) ? Ho[((size_t)i * n + (c - n - 1)) * n + r] : 0.0;  // H_{i,i+1} = block (i+1, i)^T
           }
-        } else if (c == n) {
-          v = -gv[(size_t)i * n + r];
-          if (i > 0) {
-            double s = 0.0;
-            for (int k = 0; k < n; k++) s = fma(W[k * n + r], xs[(size_t)(i - 1) * n + k], s);
-            v -= s;
-          }
-        } else {
-          v = (i < N) ? Ho[((size_t)i * n + (c - n - 1)) * n + r] : 0.0;  // H_{i,i+1} = block (i+1, i)^T
+          A[r * AW + c] = v;
         }
-        A[e] = v;
-      }
       __syncthreads();
+      // right-looking elimination on the 16 x 16 thread grid (ty: rows, tx: column strips); row k stays
+      // unscaled (R[k][c] = A[k][c] / sqrt(p_k) is applied when the block is stored): one barrier per pivot
       for (int k = 0; k < n; k++) {
         const double piv = A[k * AW + k];
         if (!(piv > 0.0)) {  // uniform: every thread reads the same LDS value
           if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
           return;
         }
-        const double inv = 1.0 / sqrt(piv);
-        // rows below the pivot: A[j][c] -= (A[k][j] / piv) * A[k][c] for c >= j (upper part) and the extras
-        const int rows = n - 1 - k;
-        for (int e = tid; e < rows * AW; e += DENSE_THREADS) {
-          const int j = k + 1 + e / AW, c = e % AW;
-          if (c < j) continue;
-          A[j * AW + c] = fma(-(A[k * AW + j] / piv), A[k * AW + c], A[j * AW + c]);
+        const double ipiv = 1.0 / piv;
+        for (int j = k + 1 + ty; j < n; j += 16) {
+          const double m = A[k * AW + j] * ipiv;
+          for (int c = tx; c < AW; c += 16)
+            if (c >= j) A[j * AW + c] = fma(-m, A[k * AW + c], A[j * AW + c]);
         }
-        __syncthreads();
-        for (int c = k + tid; c < AW; c += DENSE_THREADS) A[k * AW + c] *= inv;  // row k of R, y, W
         __syncthreads();
       }
       // keep R_i (upper), W_i for the back-substitution; y_i in xs; W_i also stays in LDS for block i+1
-      for (int e = tid; e < n * n; e += DENSE_THREADS) {
-        const int r = e / n, c = e - r * n;
-        Hd[((size_t)i * n + r) * n + c] = (c >= r) ? A[r * AW + c] : 0.0;
-        const double w = A[r * AW + n + 1 + c];
-        W[e] = w;
-        if (i < N) Ho[((size_t)i * n + r) * n + c] = w;
+      for (int r = ty; r < n; r += 16) {
+        const double isq = 1.0 / sqrt(A[r * AW + r]);
+        for (int c = tx; c < n; c += 16) {
+          Hd[((size_t)i * n + r) * n + c] = (c >= r) ? A[r * AW + c] * isq : 0.0;
+          const double w = A[r * AW + n + 1 + c] * isq;
+          W[r * n + c] = w;
+          if (i < N) Ho[((size_t)i * n + r) * n + c] = w;
+        }
+        if (tx == 0) xs[(size_t)i * n + r] = A[r * AW + n] * isq;
       }
-      if (tid < n) xs[(size_t)i * n + tid] = A[tid * AW + n];
       __syncthreads();
     }
-    // ---- backward: x_i = R_i^-1 (y_i - W_i x_{i+1})
+    // ---- backward: x_i = R_i^-1 (y_i - W_i x_{i+1}); thread r carries t_r, one barrier per unknown
+    double* xk = W;  // [n] scratch for the unknown being broadcast (W is free now); R_i is staged in A
     for (int i = N; i >= 0; i--) {
-      for (int e = tid; e < n * n; e += DENSE_THREADS) A[(e / n) * AW + (e % n)] = Hd[(size_t)i * n * n + e];
+      for (int e = tid; e < n * n; e += DENSE_THREADS) A[e] = Hd[(size_t)i * n * n + e];
+      double t = 0.0;
       if (tid < n) {
-        double t = xs[(size_t)i * n + tid];
+        t = xs[(size_t)i * n + tid];
         if (i < N) {
           const double* Wi = Ho + (size_t)i * n * n;
           for (int c = 0; c < n; c++) t = fma(-Wi[tid * n + c], xs[(size_t)(i + 1) * n + c], t);
         }
-        A[tid * AW + n] = t;
       }
       __syncthreads();
       for (int k = n - 1; k >= 0; k--) {
-        if (tid == 0) A[k * AW + n] /= A[k * AW + k];
+        if (tid == k) xk[k] = t / A[k * n + k];
         __syncthreads();
-        if (tid < k) A[tid * AW + n] = fma(-A[tid * AW + k], A[k * AW + n], A[tid * AW + n]);
-        __syncthreads();
+        if (tid < k) t = fma(-A[tid * n + k], xk[k], t);
       }
-      if (tid < n) xs[(size_t)i * n + tid] = A[tid * AW + n];
+      if (tid < n) xs[(size_t)i * n + tid] = xk[tid];
       __syncthreads();
     }
     double gd = 0.0, dd = 0.0, gg = 0.0;
