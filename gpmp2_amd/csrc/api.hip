@@ -214,6 +214,7 @@ struct gpmp2mi_plan {
   std::vector<void*> allocs;
   int* h_flags = nullptr;    // pinned + device-mapped [n_active_len]: per-pass active count, -1 = not yet known
   KernelTimer timer;
+  bool wide_dense = false;   // GPMP2MI_WIDE_DENSE=1: 8..11-dof plans through the dense block solver (A/B, fallback)
   bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
   int n_active_len = 0;
   std::vector<int> h_xp_n;   // host mirror of the extra-prior counts
@@ -897,8 +898,9 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.init, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.result, tsz));
   G2_TRY(plan_alloc(p.get(), &pb.delta, tsz));
-  G2_TRY(plan_alloc(p.get(), &pb.gvec, (size_t)B * (P.N + 1) * 16));
-  G2_TRY(plan_alloc(p.get(), &pb.htiles, P.opt_type == GPMP2MI_OPT_DOGLEG ? (size_t)B * (P.N + 1) * 512 : 1));
+  const size_t tq = wide ? 4 : 1;  // wide blocks: 2 x 2 tiles, 32-wide vectors
+  G2_TRY(plan_alloc(p.get(), &pb.gvec, (size_t)B * (P.N + 1) * (wide ? 32 : 16)));
+  G2_TRY(plan_alloc(p.get(), &pb.htiles, P.opt_type == GPMP2MI_OPT_DOGLEG ? (size_t)B * (P.N + 1) * 512 * tq : 1));
   G2_TRY(plan_alloc(p.get(), &pb.hgpart, (size_t)B * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
@@ -924,8 +926,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * P.GPREC * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * P.GPREC * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256));
-  G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768));
+  G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256 * tq));
+  G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768 * tq));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.prev_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.last_err, B));
@@ -941,6 +943,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   {
     const char* e = getenv("GPMP2MI_GENERIC_GN");
     p->generic_gn = e && e[0] == '1';
+    const char* wd = getenv("GPMP2MI_WIDE_DENSE");
+    p->wide_dense = wd && wd[0] == '1';
     const int cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
     // passes: GN one per iteration (+1); LM up to ~5 lambda retries per iterate; Dogleg up to ~16 halvings
     const int mult = P.opt_type == GPMP2MI_OPT_LM ? 6 : P.opt_type == GPMP2MI_OPT_DOGLEG ? 18 : 1;
@@ -1062,12 +1066,22 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
     G2_TRY(launch_decide(P, pb, 0, true, st));
     p->timer.close(st);
     for (int pass = 1; pass < max_pass; pass++) {
-      if (P.wide) {
-        // blocks wider than one tile (8 <= dof <= 11): dense normal equations + dense block Cholesky
+      if (P.wide && p->wide_dense) {
+        // fallback / A-B: dense normal equations + dense block Cholesky in natural order
         p->timer.begin("export_dense", st);
         G2_TRY(launch_export_normal_eq(P, pb, pb.cur, 0, pb.wHd, pb.wHo, pb.wg, st, pb.active));
         p->timer.begin("solve_dense", st);
         G2_TRY(launch_solve_dense(P, pb, st));
+      } else if (P.wide) {
+        // blocks wider than one tile (8 <= dof <= 11): the same cyclic reduction on 2x2 tiles
+        p->timer.begin("assemble_wide", st);
+        G2_TRY(launch_assemble_wide(P, pb, pb.cur, 0, pb.active, st));
+        if (P.opt_type == GPMP2MI_OPT_DOGLEG) {
+          p->timer.begin("ghg_wide", st);
+          G2_TRY(launch_ghg_wide(P, pb, st));
+        }
+        p->timer.begin("solve_step_wide", st);
+        G2_TRY(launch_solve_step_wide(P, pb, st));
       } else {
         p->timer.begin("assemble", st);
         G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));

@@ -828,4 +828,6 @@ int launch_debug_crosslane(const double* in, double* out, hipStream_t st) {
   return GPMP2MI_OK;
 }
 
+#include "wide_cr.h"
+
 }  // namespace g2

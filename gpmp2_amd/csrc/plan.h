@@ -112,6 +112,11 @@ int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+// wide_cr.h (8 <= dof <= 11 on 2x2 tiles)
+int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                         const int* active, hipStream_t st);
+int launch_ghg_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_solve_step_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                         double* err, hipStream_t st);
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,

@@ -1,0 +1,536 @@
+// wide_cr.h -- cyclic reduction with blocks wider than one tile (8 <= dof <= 11, n = 2 dof <= 22).
+//
+// Included at the end of cr_kernels.hip (inside namespace g2).  A block is a 32 x 32 matrix held as
+// 2 x 2 MFMA-layout tiles (WTile); element (row, col) lives in tile (row >> 4, col >> 4).  The right-hand
+// side rides in column 31.  Everything mirrors the one-tile kernels: k_assemble_wide forms the block of
+// one support state (four Assembler passes with tile offsets) and eliminates the odd blocks (level 1);
+// k_solve_step_wide runs levels 2.. of the reduction, the back-substitution and the trial-step tail of
+// the GN / LM / Dogleg driver.  Not yet here: level-2 fusion into the assemble kernel, the chip-wide
+// back-substitution tail, the fused GN step kernel (GN runs through the trial-step driver).
+#pragma once
+
+struct WTile {
+  Tile t[2][2];
+};
+constexpr int WTILE_DBL = 4 * TILE_DBL;  // 1024 doubles
+constexpr int WRHS = 31;                 // column that carries the right-hand side
+constexpr int WX = 32;                   // stride of a block's solution in LDS / gvec
+
+__device__ __forceinline__ WTile wtile_load(const double* p, int lane) {
+  WTile W;
+#pragma unroll
+  for (int q = 0; q < 4; q++) W.t[q >> 1][q & 1] = tile_load(p + q * TILE_DBL, lane);
+  return W;
+}
+__device__ __forceinline__ void wtile_store(double* p, const WTile& W, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) tile_store(p + q * TILE_DBL, W.t[q >> 1][q & 1], lane);
+}
+__device__ __forceinline__ WTile wtile_zero() {
+  WTile W;
+#pragma unroll
+  for (int q = 0; q < 4; q++) W.t[q >> 1][q & 1] = tile_zero();
+  return W;
+}
+__device__ __forceinline__ WTile wtile_identity(int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  WTile W = wtile_zero();
+#pragma unroll
+  for (int k = 0; k < 4; k++) W.t[0][0].r[k] = W.t[1][1].r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+  return W;
+}
+
+// (A^T B)(i, j) = sum_k A(k, i)^T B(k, j) over the two tile rows
+__device__ __forceinline__ Tile wtile_atb_ij(const WTile& A, const WTile& B, int i, int j) {
+  v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.t[kt][i].r[k], B.t[kt][j].r[k], acc, 0, 0, 0);
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = acc[k];
+  return T;
+}
+
+// S -= A^T A restricted to real rows (< n) and to the matrix + rhs columns
+template <int n>
+__device__ __forceinline__ void wschur_sub(WTile& S, const WTile& A, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      if (16 * ti >= n) continue;
+      const Tile T = wtile_atb_ij(A, A, ti, tj);
+      const int col = 16 * tj + c;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((16 * ti + g + 4 * k) < n && (col < n || col == WRHS)) S.t[ti][tj].r[k] -= T.r[k];
+    }
+}
+// -(A^T B) restricted to the n x n matrix part
+template <int n>
+__device__ __forceinline__ WTile wcoupling(const WTile& A, const WTile& B, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  WTile C = wtile_zero();
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      if (16 * ti >= n || 16 * tj >= n) continue;
+      const Tile T = wtile_atb_ij(A, B, ti, tj);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        C.t[ti][tj].r[k] = ((16 * ti + g + 4 * k) < n && (16 * tj + c) < n) ? -T.r[k] : 0.0;
+    }
+  return C;
+}
+
+// Eliminate the n pivots of S = [S | b] (rhs in column WRHS) and apply the row operations to the two coupling
+// blocks and to V (identity on entry); same contract as tile_eliminate3.
+template <int n>
+__device__ __forceinline__ bool wtile_eliminate3(WTile& S, WTile& Cl, WTile& Cr, WTile& V, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  double piv_of_row[2][4];
+#pragma unroll
+  for (int q = 0; q < 8; q++) piv_of_row[q >> 2][q & 3] = 1.0;
+  bool ok = true;
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, tp = j >> 4, jl = j & 15, gj = jl & 3, rj = jl >> 2;
+    const int src = gj * 16 + c;
+    double rowS[2], rowL[2], rowR[2], rowV[2];
+#pragma unroll
+    for (int tc = 0; tc < 2; tc++) {
+      rowS[tc] = __shfl(S.t[tp][tc].r[rj], src, 64);
+      rowL[tc] = __shfl(Cl.t[tp][tc].r[rj], src, 64);
+      rowR[tc] = __shfl(Cr.t[tp][tc].r[rj], src, 64);
+      rowV[tc] = __shfl(V.t[tp][tc].r[rj], src, 64);
+    }
+    const double piv = readlane_d(S.t[tp][tp].r[rj], gj * 16 + jl);
+    ok = ok && (piv > 0.0);
+    const double inv = fast_rcp(piv);
+    if (g == gj) piv_of_row[tp][rj] = piv;
+#pragma unroll
+    for (int tr = tp; tr < 2; tr++) {
+      if (16 * tr >= n) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (tr == tp && 4 * k + 3 <= jl) continue;  // rows of this register are all at or above the pivot
+        const double m = bcast_in_row<jl>(S.t[tr][tp].r[k]);
+        const double f = (16 * tr + g + 4 * k > j) ? m * inv : 0.0;
+#pragma unroll
+        for (int tc = 0; tc < 2; tc++) {
+          S.t[tr][tc].r[k] = fma(-f, rowS[tc], S.t[tr][tc].r[k]);
+          Cl.t[tr][tc].r[k] = fma(-f, rowL[tc], Cl.t[tr][tc].r[k]);
+          Cr.t[tr][tc].r[k] = fma(-f, rowR[tc], Cr.t[tr][tc].r[k]);
+          V.t[tr][tc].r[k] = fma(-f, rowV[tc], V.t[tr][tc].r[k]);
+        }
+      }
+    }
+  });
+#pragma unroll
+  for (int tr = 0; tr < 2; tr++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double s = 1.0 / sqrt(piv_of_row[tr][k]);
+      const double y = S.t[tr][1].r[k] * s;  // meaningful in the rhs column only
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) {
+        const bool rhs = (tc == 1 && c == 15);
+        Cl.t[tr][tc].r[k] = rhs ? y : Cl.t[tr][tc].r[k] * s;
+        Cr.t[tr][tc].r[k] = rhs ? y : Cr.t[tr][tc].r[k] * s;
+        V.t[tr][tc].r[k] *= s;
+      }
+    }
+  return ok;
+}
+
+// x_j = V^T (y - Wl x_l - Wr x_r); xl[tc] / xr[tc] = neighbour solutions at column 16 tc + c; returns x[tc]
+template <int n>
+__device__ __forceinline__ void wcr_backsolve(const WTile& Wl, const WTile& Wr, const WTile& V, const double (&xl)[2],
+                                              const double (&xr)[2], int lane, double (&x)[2]) {
+  const int c = lane & 15;
+  double t[2][4];
+#pragma unroll
+  for (int tr = 0; tr < 2; tr++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      double acc = 0.0;
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) {
+        const int col = 16 * tc + c;
+        double v;
+        if (col == WRHS) v = -Wl.t[tr][tc].r[k];  // -y (same in both blocks)
+        else v = (col < n) ? fma(Wl.t[tr][tc].r[k], xl[tc], Wr.t[tr][tc].r[k] * xr[tc]) : 0.0;
+        acc += row_sum16(v);
+      }
+      t[tr][k] = -acc;
+    }
+#pragma unroll
+  for (int tc = 0; tc < 2; tc++) {
+    double a = 0.0;
+#pragma unroll
+    for (int tr = 0; tr < 2; tr++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) a = fma(V.t[tr][tc].r[k], t[tr][k], a);
+    x[tc] = sum_rows(a);
+  }
+}
+
+// =============================================================================== assemble (wide)
+template <int D, bool LIE>
+__global__ __launch_bounds__(64) void k_assemble_wide(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                       const double* __restrict__ traj, int bufsel,
+                                                       const int* __restrict__ active) {
+  constexpr int n = 2 * D;
+  using Asm = Assembler<D, LIE>;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  if (active && !active[b]) return;
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG && active && pb.phase[b] != 0) return;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  extern __shared__ __attribute__((aligned(16))) double asm_smem[];
+  const double* rec = rec_of(pb, pb.which[b], bufsel);
+  const double* gpu = gpu_of(pb, pb.which[b], bufsel);
+  Asm as(P, pb, rec, gpu, b, lane);
+  const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
+  as.stage2(i, slot0, slot1);
+  __syncthreads();
+  const bool odd = (i & 1) != 0;
+  const bool want_c = odd || P.opt_type == GPMP2MI_OPT_DOGLEG;
+  const double* zi = traj + ((size_t)b * (N + 1) + i) * n;
+  WTile S, Cl, Cr;
+  static_for<0, 4>([&](auto qc) {  // forced unrolling: the four tiles must stay in registers
+    constexpr int ti = decltype(qc)::value >> 1, tj = decltype(qc)::value & 1;
+    Asm at(P, pb, rec, gpu, b, lane, 16 * ti, 16 * tj, WRHS);
+    at.build_tiles(i, slot0, slot1, zi, S.t[ti][tj], Cl.t[ti][tj], Cr.t[ti][tj], want_c);
+  });
+  // gradient g_i (the rhs column holds -g_i)
+  if (c == 15) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) pb.gvec[((size_t)b * (N + 1) + i) * WX + 16 * ti + g + 4 * k] = -S.t[ti][1].r[k];
+  }
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG) {  // un-eliminated blocks for g^T H g
+    double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * WTILE_DBL;
+    wtile_store(ht, S, lane);
+    wtile_store(ht + WTILE_DBL, Cr, lane);
+  }
+  if (P.opt_type == GPMP2MI_OPT_LM) {
+    const double lam = pb.lambda[b];
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (g + 4 * k == c && 16 * ti + c < n) S.t[ti][ti].r[k] += lam;
+  }
+  if (!odd) {
+    wtile_store(pb.tiles + ((size_t)b * (N + 1) + i) * WTILE_DBL, S, lane);
+  } else {
+    WTile V = wtile_identity(lane);
+    const bool ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane);
+    double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * WTILE_DBL;
+    wtile_store(f, Cl, lane);
+    wtile_store(f + WTILE_DBL, Cr, lane);
+    wtile_store(f + 2 * WTILE_DBL, V, lane);
+    if (!ok && lane == 0) pb.notspd[b] = 1;
+  }
+}
+
+int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
+                         const int* active, hipStream_t st) {
+  const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
+  switch (hp.D) {
+#define G2_ASMW_CASE(DD) \
+  case DD:                                                                                      \
+    if (hp.lie) k_assemble_wide<DD, true><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, active); \
+    else k_assemble_wide<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, active);       \
+    break;
+    G2_ASMW_CASE(8) G2_ASMW_CASE(9) G2_ASMW_CASE(10) G2_ASMW_CASE(11)
+#undef G2_ASMW_CASE
+    default:
+      set_error("wide blocks are instantiated for 8 <= dof <= 11");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// g^T H g share of block i from the blocks saved by k_assemble_wide (Dogleg)
+template <int D>
+__global__ __launch_bounds__(64) void k_ghg_wide(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int b = blockIdx.x / (N + 1), i = blockIdx.x - b * (N + 1);
+  if (!pb.active[b] || pb.phase[b] != 0) return;
+  const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
+  const double* ht = pb.htiles + ((size_t)b * (N + 1) + i) * 2 * WTILE_DBL;
+  const WTile Dt = wtile_load(ht, lane), Ht = wtile_load(ht + WTILE_DBL, lane);
+  const double* gv = pb.gvec + ((size_t)b * (N + 1) + i) * WX;
+  double acc = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      const int col = 16 * tj + c;
+      const double gi_c = (col < n) ? gv[col] : 0.0;
+      const double gn_c = (col < n && i < N) ? gv[WX + col] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int rho = 16 * ti + g + 4 * k;
+        const double gi_r = (rho < n) ? gv[rho] : 0.0;
+        if (col < n) acc += gi_r * (Dt.t[ti][tj].r[k] * gi_c + 2.0 * Ht.t[ti][tj].r[k] * gn_c);
+      }
+    }
+  acc = wave_sum(acc);
+  if (lane == 0) pb.hgpart[(size_t)b * P.Npad + i] = acc;
+}
+
+int launch_ghg_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B * (hp.N + 1)), block(64);
+  switch (hp.D) {
+#define G2_GHGW_CASE(DD) \
+  case DD: k_ghg_wide<DD><<<grid, block, 0, st>>>(pb.params, pb); break;
+    G2_GHGW_CASE(8) G2_GHGW_CASE(9) G2_GHGW_CASE(10) G2_GHGW_CASE(11)
+#undef G2_GHGW_CASE
+    default:
+      set_error("wide blocks are instantiated for 8 <= dof <= 11");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+// =============================================================================== solve step (wide)
+constexpr int WCR_WAVES = 8;  // 16 tiles of state per elimination: 2 wavefronts per SIMD keep 256 VGPRs each
+
+template <int n>
+__device__ __forceinline__ bool wcr_forward(const PlanBuffers& pb, int b, int N, int tid) {
+  const int w = tid >> 6, lane = tid & 63;
+  double* tiles = pb.tiles + (size_t)b * (N + 1) * WTILE_DBL;
+  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * WTILE_DBL;
+  bool ok = true;
+  int hfinal = 1;
+  while (hfinal <= N) hfinal <<= 1;
+  for (int h = 2; h <= hfinal; h <<= 1) {
+    const bool final = (h == hfinal);
+    const int hh = h >> 1;
+    const int countE = final ? 1 : ((N / h) + 1) / 2;
+    const int countU = final ? 0 : (N / (2 * h)) + 1;
+    for (int idx = w; idx < countE + countU; idx += WCR_WAVES) {
+      const bool elim = idx < countE;
+      const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
+      WTile S = wtile_load(tiles + (size_t)j * WTILE_DBL, lane);
+      WTile Cl = wtile_zero(), Cr = wtile_zero();
+      const int jm = j - hh, jp = j + hh;
+      if (jm >= 0) {
+        const WTile Wr = wtile_load(fac + ((size_t)jm * 3 + 1) * WTILE_DBL, lane);
+        wschur_sub<n>(S, Wr, lane);
+        if (elim && !final) {
+          const WTile Wl = wtile_load(fac + (size_t)jm * 3 * WTILE_DBL, lane);
+          Cl = wcoupling<n>(Wr, Wl, lane);  // rows j, cols j - h
+        }
+      }
+      if (jp <= N) {
+        const WTile Wl = wtile_load(fac + (size_t)jp * 3 * WTILE_DBL, lane);
+        wschur_sub<n>(S, Wl, lane);
+        if (elim && !final && j + h <= N) {
+          const WTile Wr = wtile_load(fac + ((size_t)jp * 3 + 1) * WTILE_DBL, lane);
+          Cr = wcoupling<n>(Wl, Wr, lane);  // rows j, cols j + h
+        }
+      }
+      if (!elim) {
+        wtile_store(tiles + (size_t)j * WTILE_DBL, S, lane);
+        continue;
+      }
+      WTile V = wtile_identity(lane);
+      ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
+      double* f = fac + (size_t)j * 3 * WTILE_DBL;
+      wtile_store(f, Cl, lane);
+      wtile_store(f + WTILE_DBL, Cr, lane);
+      wtile_store(f + 2 * WTILE_DBL, V, lane);
+    }
+    __syncthreads();
+  }
+  return ok;
+}
+
+template <int n>
+__device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs) {
+  const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * WTILE_DBL;
+  int hfinal = 1;
+  while (hfinal <= N) hfinal <<= 1;
+  for (int h = hfinal; h >= 1; h >>= 1) {
+    const bool final = (h == hfinal);
+    const int count = final ? 1 : ((N / h) + 1) / 2;
+    for (int idx = w; idx < count; idx += WCR_WAVES) {
+      const int j = final ? 0 : h * (2 * idx + 1);
+      const double* f = fac + (size_t)j * 3 * WTILE_DBL;
+      const WTile Wl = wtile_load(f, lane), Wr = wtile_load(f + WTILE_DBL, lane), V = wtile_load(f + 2 * WTILE_DBL, lane);
+      const int jl = j - h, jr = j + h;
+      double xl[2], xr[2], x[2];
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) {
+        xl[tc] = (!final && jl >= 0) ? xs[jl * WX + 16 * tc + c] : 0.0;
+        xr[tc] = (!final && jr <= N) ? xs[jr * WX + 16 * tc + c] : 0.0;
+      }
+      wcr_backsolve<n>(Wl, Wr, V, xl, xr, lane, x);
+      if (g == 0) {
+#pragma unroll
+        for (int tc = 0; tc < 2; tc++) xs[j * WX + 16 * tc + c] = (16 * tc + c < n) ? x[tc] : 0.0;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ double wblock_sum(double v, double* red, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int k = 0; k < WCR_WAVES; k++) t += red[k];
+  return t;
+}
+
+// k_solve_step for wide blocks: same contract (delta, trial point, step-control scalars)
+template <int D>
+__global__ __launch_bounds__(64 * WCR_WAVES) void k_solve_step_wide(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (!pb.active[b]) return;
+  const int N = P.N;
+  const size_t tsz = (size_t)(N + 1) * n;
+  const double* cur = pb.cur + b * tsz;
+  double* trial = pb.trial + b * tsz;
+  double* delta = pb.delta + b * tsz;
+  double* sc = pb.scal + (size_t)b * SC_COUNT;
+  const double* gv = pb.gvec + (size_t)b * (N + 1) * WX;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* xs = smem;
+  double* red = smem + (size_t)(N + 1) * WX;
+  int* flags = reinterpret_cast<int*>(red + WCR_WAVES);
+  const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
+  const bool resolve = !(dogleg && pb.phase[b] != 0);
+  if (tid == 0) flags[1] = 0;
+  __syncthreads();
+  if (resolve) {
+    const bool ok = wcr_forward<n>(pb, b, N, tid);
+    if ((!ok && (tid & 63) == 0) || (tid == 0 && pb.notspd[b])) flags[1] = 1;
+    __syncthreads();
+    if (flags[1]) {
+      if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
+      return;
+    }
+    wcr_backward<n>(pb, b, N, tid, xs);
+    double gd = 0.0, dd = 0.0, gg = 0.0;
+    for (size_t k = tid; k < tsz; k += blockDim.x) {
+      const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+      const double x = xs[i * WX + rho], gk = gv[i * WX + rho];
+      delta[k] = x;
+      gd = fma(gk, x, gd);
+      dd = fma(x, x, dd);
+      gg = fma(gk, gk, gg);
+    }
+    gd = wblock_sum(gd, red, tid);
+    dd = wblock_sum(dd, red, tid);
+    gg = wblock_sum(gg, red, tid);
+    if (tid == 0) {
+      sc[SC_GD] = gd;
+      sc[SC_DD] = dd;
+      sc[SC_GG] = gg;
+      sc[SC_GN] = gd;
+      sc[SC_NN] = dd;
+    }
+    if (dogleg) {
+      double acc = 0.0;
+      for (int i = tid; i <= N; i += blockDim.x) acc += pb.hgpart[(size_t)b * P.Npad + i];
+      acc = wblock_sum(acc, red, tid);
+      if (tid == 0) sc[SC_GHG] = acc;
+    }
+    __syncthreads();
+  }
+  if (!dogleg) {
+    for (size_t k = tid; k < tsz; k += blockDim.x) {
+      const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+      const double* zs = cur + (size_t)i * n;
+      const double* dz = xs + i * WX;
+      trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
+    }
+    return;
+  }
+  // ---- Powell dogleg point for trust radius pb.lambda[b]  (same blend as k_solve_step)
+  const double Delta = pb.lambda[b];
+  const double gg = sc[SC_GG], gHg = sc[SC_GHG], gn = sc[SC_GN], nn = sc[SC_NN];
+  const double step = -gg / gHg;
+  const double uu = step * step * gg, un = step * gn;
+  const double DeltaSq = Delta * Delta;
+  double cu, cn, q;
+  if (DeltaSq < uu) {
+    const double k = sqrt(DeltaSq / uu);
+    cu = k * step;
+    cn = 0.0;
+    q = cu * gg + 0.5 * cu * cu * gHg;
+  } else if (DeltaSq < nn) {
+    const double a = uu - 2. * un + nn, bq = 2. * (un - uu), cq = uu - Delta * Delta;
+    const double sq = sqrt(bq * bq - 4 * a * cq);
+    const double tau1 = (-bq + sq) / (2. * a), tau2 = (-bq - sq) / (2. * a);
+    const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
+    cu = (1. - tau) * step;
+    cn = tau;
+    q = cu * gg + cn * gn + 0.5 * (cu * cu * gHg - 2.0 * cu * cn * gg - cn * cn * gn);
+  } else {
+    cu = 0.0;
+    cn = 1.0;
+    q = 0.5 * gn;
+  }
+  double xn = 0.0;
+  __syncthreads();
+  for (size_t k = tid; k < tsz; k += blockDim.x) {
+    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+    const double x = cu * gv[i * WX + rho] + cn * delta[k];
+    xs[i * WX + rho] = x;
+    xn = fma(x, x, xn);
+  }
+  __syncthreads();
+  for (size_t k = tid; k < tsz; k += blockDim.x) {
+    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
+    const double* zs = cur + (size_t)i * n;
+    const double* dz = xs + i * WX;
+    trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
+  }
+  xn = wblock_sum(xn, red, tid);
+  if (tid == 0) {
+    sc[SC_Q] = q;
+    sc[SC_XNORM] = sqrt(xn);
+  }
+}
+
+int launch_solve_step_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B), block(64 * WCR_WAVES);
+  const size_t shmem = ((size_t)(hp.N + 1) * WX + WCR_WAVES + 2) * sizeof(double);
+  if (shmem > 150 * 1024) {
+    set_error("total_step too large for the LDS-resident solution buffer");
+    return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  switch (hp.D) {
+#define G2_SSW_CASE(DD) \
+  case DD: k_solve_step_wide<DD><<<grid, block, shmem, st>>>(pb.params, pb); break;
+    G2_SSW_CASE(8) G2_SSW_CASE(9) G2_SSW_CASE(10) G2_SSW_CASE(11)
+#undef G2_SSW_CASE
+    default:
+      set_error("wide blocks are instantiated for 8 <= dof <= 11");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
