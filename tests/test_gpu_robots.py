@@ -220,3 +220,20 @@ def test_wide_robot_linearize_and_plans(engine, oracle, name):
         assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
         np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
         np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+def test_wide_dense_fallback_agrees(engine, oracle, monkeypatch):
+    """GPMP2MI_WIDE_DENSE=1: the independent dense block-Cholesky implementation of the 8..11-dof solve"""
+    model = _wide_models()["mobile WAM (dof 10)"]
+    p = _tree_problem(model, N=10, inter=2, opt="LM")
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+    tiles = engine.batch_optimize(r, s, p.setting, *args, p.init)
+    monkeypatch.setenv("GPMP2MI_WIDE_DENSE", "1")
+    dense = engine.batch_optimize(r, s, p.setting, *args, p.init)
+    for res in (tiles, dense):
+        assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+        np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(tiles["traj"], dense["traj"], atol=1e-7)
