@@ -6,6 +6,8 @@
 //   gpmp2::TrajOptimizerSetting                         gpmp2/planner/TrajOptimizerSetting.h:17-100
 //   gpmp2::BatchTrajOptimize3DArm / 2DArm               gpmp2/planner/BatchTrajOptimizer.h:43-56
 //   gpmp2::CollisionCost3DArm / 2DArm                   gpmp2/planner/BatchTrajOptimizer.h:135-147
+//   gpmp2::Pose2MobileArm / Pose2MobileArmModel, BatchTrajOptimizePose2MobileArm(2D)   gpmp2/planner/BatchTrajOptimizer.h:57-73
+//   gpmp2::Obstacle(Planar)SDFFactorArm / ...Pose2MobileArm, GoalFactorArm, GaussianPriorWorkspacePoseArm, SelfCollisionArm
 //   gpmp2::interpolateArmTraj / interpolatePose2MobileArmTraj  gpmp2/planner/TrajUtils.cpp:96-236
 //   gpmp2::ISAM2TrajOptimizer2DArm / 3DArm              gpmp2/planner/ISAM2TrajOptimizer.h:143-156
 //   gpmp2::initArmTrajStraightLine                      gpmp2/planner/TrajUtils.cpp:25-50
@@ -132,6 +134,63 @@ class ArmModel {
 
  private:
   Arm arm_;
+  BodySphereVector spheres_;
+  gpmp2mi_robot* h_ = nullptr;
+};
+
+/// gpmp2::Pose2MobileArm  gpmp2/kinematics/Pose2MobileArm.h:22-70 (state [x, y, theta, q...])
+class Pose2MobileArm {
+ public:
+  explicit Pose2MobileArm(const Arm& arm, const Pose3& base_T_arm = Pose3()) : arm_(arm), base_T_arm_(base_T_arm) {}
+  std::size_t dof() const { return arm_.dof() + 3; }
+  std::size_t nr_links() const { return arm_.dof() + 1; }
+  const Arm& arm() const { return arm_; }
+  const Pose3& base_T_arm() const { return base_T_arm_; }
+
+ private:
+  Arm arm_;
+  Pose3 base_T_arm_;
+};
+
+/// RobotModel<Pose2MobileArm>: owns the device-side robot handle; sphere link 0 = vehicle base
+class Pose2MobileArmModel {
+ public:
+  Pose2MobileArmModel(const Pose2MobileArm& marm, const BodySphereVector& spheres) : marm_(marm), spheres_(spheres) {
+    gpmp2mi_robot_desc d{};
+    d.kind = GPMP2MI_ROBOT_POSE2_MOBILE_ARM;
+    d.dof = static_cast<int>(marm.dof());
+    d.arm_dof = static_cast<int>(marm.arm().dof());
+    d.a = marm_.arm().a().data();
+    d.alpha = marm_.arm().alpha().data();
+    d.d = marm_.arm().d().data();
+    d.theta_bias = marm_.arm().theta_bias().data();
+    for (int i = 0; i < 16; i++) {
+      d.base_pose[i] = marm_.base_T_arm().m[i];
+      d.base_pose2[i] = d.base_pose3[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    }
+    std::vector<int> link;
+    Vector radius, center;
+    for (const auto& sp : spheres_) {
+      link.push_back(static_cast<int>(sp.link_id));
+      radius.push_back(sp.radius);
+      center.insert(center.end(), sp.center.begin(), sp.center.end());
+    }
+    d.nr_spheres = static_cast<int>(spheres_.size());
+    d.sphere_link = link.data();
+    d.sphere_radius = radius.data();
+    d.sphere_center = center.data();
+    check(gpmp2mi_robot_create(&d, &h_), "gpmp2mi_robot_create");
+  }
+  Pose2MobileArmModel(const Pose2MobileArmModel&) = delete;
+  Pose2MobileArmModel& operator=(const Pose2MobileArmModel&) = delete;
+  ~Pose2MobileArmModel() { gpmp2mi_robot_destroy(h_); }
+  std::size_t dof() const { return marm_.dof(); }
+  std::size_t nr_body_spheres() const { return spheres_.size(); }
+  const Pose2MobileArm& fk_model() const { return marm_; }
+  const gpmp2mi_robot* handle() const { return h_; }
+
+ private:
+  Pose2MobileArm marm_;
   BodySphereVector spheres_;
   gpmp2mi_robot* h_ = nullptr;
 };
@@ -331,6 +390,112 @@ inline Trajectory BatchTrajOptimize2DArm(const ArmModel& arm, const PlanarSDF& s
   return internal::BatchTrajOptimize(arm.handle(), sdf.handle(), arm.dof(), start_conf, start_vel, end_conf, end_vel,
                                      init_values, setting, iterations, final_error);
 }
+/// gpmp2::BatchTrajOptimizePose2MobileArm  gpmp2/planner/BatchTrajOptimizer.cpp:79-89
+inline Trajectory BatchTrajOptimizePose2MobileArm(const Pose2MobileArmModel& marm, const SignedDistanceField& sdf,
+                                                  const Vector& start_conf, const Vector& start_vel, const Vector& end_conf,
+                                                  const Vector& end_vel, const Trajectory& init_values,
+                                                  const TrajOptimizerSetting& setting, int* iterations = nullptr,
+                                                  double* final_error = nullptr) {
+  return internal::BatchTrajOptimize(marm.handle(), sdf.handle(), marm.dof(), start_conf, start_vel, end_conf, end_vel,
+                                     init_values, setting, iterations, final_error);
+}
+/// gpmp2::BatchTrajOptimizePose2MobileArm2D  gpmp2/planner/BatchTrajOptimizer.cpp:66-76
+inline Trajectory BatchTrajOptimizePose2MobileArm2D(const Pose2MobileArmModel& marm, const PlanarSDF& sdf,
+                                                    const Vector& start_conf, const Vector& start_vel,
+                                                    const Vector& end_conf, const Vector& end_vel,
+                                                    const Trajectory& init_values, const TrajOptimizerSetting& setting,
+                                                    int* iterations = nullptr, double* final_error = nullptr) {
+  return internal::BatchTrajOptimize(marm.handle(), sdf.handle(), marm.dof(), start_conf, start_vel, end_conf, end_vel,
+                                     init_values, setting, iterations, final_error);
+}
+
+// ---- factors: evaluateError(x..., H...) of the reference's NoiseModelFactors, one evaluation per call ----------
+namespace internal {
+template <class ROBOT, class SDF>
+class ObstacleSDFFactor {  // gpmp2/obstacle/ObstacleSDFFactor.h:27-100, ObstaclePlanarSDFFactor.h:27-98
+ public:
+  ObstacleSDFFactor(std::size_t /*poseKey*/, const ROBOT& robot, const SDF& sdf, double /*cost_sigma*/, double epsilon)
+      : robot_(robot), sdf_(sdf), epsilon_(epsilon) {}
+  /// unwhitened error [nr_body_spheres]; H1 (optional) row-major [nr_body_spheres][dof]
+  Vector evaluateError(const Vector& conf, Vector* H1 = nullptr) const {
+    if (conf.size() != robot_.dof()) throw std::runtime_error("[ObstacleSDFFactor] conf dim does not fit dof");
+    Vector err(robot_.nr_body_spheres());
+    if (H1) H1->assign(err.size() * robot_.dof(), 0.0);
+    check(gpmp2mi_obstacle_factor(robot_.handle(), sdf_.handle(), epsilon_, 1, conf.data(), err.data(),
+                                  H1 ? H1->data() : nullptr),
+          "gpmp2mi_obstacle_factor");
+    return err;
+  }
+
+ private:
+  const ROBOT& robot_;
+  const SDF& sdf_;
+  double epsilon_;
+};
+}  // namespace internal
+typedef internal::ObstacleSDFFactor<ArmModel, SignedDistanceField> ObstacleSDFFactorArm;
+typedef internal::ObstacleSDFFactor<ArmModel, PlanarSDF> ObstaclePlanarSDFFactorArm;
+typedef internal::ObstacleSDFFactor<Pose2MobileArmModel, SignedDistanceField> ObstacleSDFFactorPose2MobileArm;
+typedef internal::ObstacleSDFFactor<Pose2MobileArmModel, PlanarSDF> ObstaclePlanarSDFFactorPose2MobileArm;
+
+/// gpmp2::GoalFactorArm  gpmp2/kinematics/GoalFactorArm.h:24-100
+class GoalFactorArm {
+ public:
+  GoalFactorArm(std::size_t /*poseKey*/, const ArmModel& arm, const std::array<double, 3>& dest_point)
+      : arm_(arm), dest_(dest_point) {}
+  Vector evaluateError(const Vector& conf, Vector* H1 = nullptr) const {
+    Vector err(3);
+    if (H1) H1->assign(3 * arm_.dof(), 0.0);
+    check(gpmp2mi_goal_factor_arm(arm_.handle(), dest_.data(), 1, conf.data(), err.data(), H1 ? H1->data() : nullptr),
+          "gpmp2mi_goal_factor_arm");
+    return err;
+  }
+
+ private:
+  const ArmModel& arm_;
+  std::array<double, 3> dest_;
+};
+
+/// gpmp2::GaussianPriorWorkspacePoseArm  gpmp2/kinematics/GaussianPriorWorkspacePose.h:24-93
+class GaussianPriorWorkspacePoseArm {
+ public:
+  GaussianPriorWorkspacePoseArm(std::size_t /*poseKey*/, const ArmModel& arm, int joint, const Pose3& des_pose)
+      : arm_(arm), joint_(joint), des_(des_pose) {}
+  Vector evaluateError(const Vector& conf, Vector* H1 = nullptr) const {
+    Vector err(6);
+    if (H1) H1->assign(6 * arm_.dof(), 0.0);
+    check(gpmp2mi_workspace_prior_factor(arm_.handle(), GPMP2MI_WORKSPACE_POSE, joint_, des_.m.data(), 1, conf.data(),
+                                         err.data(), H1 ? H1->data() : nullptr),
+          "gpmp2mi_workspace_prior_factor");
+    return err;
+  }
+
+ private:
+  const ArmModel& arm_;
+  int joint_;
+  Pose3 des_;
+};
+
+/// gpmp2::SelfCollisionArm  gpmp2/obstacle/SelfCollision.h:27-140; data rows = (sphere A, sphere B, epsilon, sigma)
+class SelfCollisionArm {
+ public:
+  SelfCollisionArm(std::size_t /*poseKey*/, const ArmModel& arm, const Vector& data_row_major) : arm_(arm), data_(data_row_major) {
+    if (data_.size() % 4) throw std::runtime_error("[SelfCollision] data must have 4 columns");
+  }
+  Vector evaluateError(const Vector& conf, Vector* H = nullptr) const {
+    const int np = static_cast<int>(data_.size() / 4);
+    Vector err(np);
+    if (H) H->assign(np * arm_.dof(), 0.0);
+    check(gpmp2mi_self_collision_factor(arm_.handle(), np, data_.data(), 1, conf.data(), err.data(), H ? H->data() : nullptr),
+          "gpmp2mi_self_collision_factor");
+    return err;
+  }
+
+ private:
+  const ArmModel& arm_;
+  Vector data_;
+};
+
 /// gpmp2::CollisionCost3DArm / 2DArm  gpmp2/planner/BatchTrajOptimizer-inl.h:87-100
 inline double CollisionCost3DArm(const ArmModel& arm, const SignedDistanceField& sdf, const Trajectory& result,
                                  const TrajOptimizerSetting&) {

@@ -38,6 +38,38 @@ int main() {
     const Trajectory dense = interpolateArmTraj(out, {}, 0.2, 4);
     if (dense.total_step != 50 || std::fabs(dense.x(50)[0] - out.x(10)[0]) > 0 || std::fabs(dense.x(5)[1] - out.x(1)[1]) > 0) return 5;
     std::printf("DENSE states=%zu x_27=(%.4f, %.4f)\n", dense.total_step + 1, dense.x(27)[0], dense.x(27)[1]);
+    // factor classes: obstacle factor + numerical Jacobian, goal factor
+    ObstaclePlanarSDFFactorArm of(0, model, sdf, 0.1, 0.2);
+    const Vector q{1.0, 0.35};
+    Vector H;
+    const Vector e0 = of.evaluateError(q, &H);
+    double worst = 0.0;
+    for (int k = 0; k < 2; k++) {
+      Vector qp = q, qm = q;
+      qp[k] += 1e-6;
+      qm[k] -= 1e-6;
+      const Vector ep = of.evaluateError(qp), em = of.evaluateError(qm);
+      for (std::size_t sidx = 0; sidx < e0.size(); sidx++)
+        worst = std::fmax(worst, std::fabs((ep[sidx] - em[sidx]) / 2e-6 - H[sidx * 2 + k]));
+    }
+    GoalFactorArm gf(0, model, {2.0, 0.0, 0.0});
+    const Vector ge = gf.evaluateError({0.0, 0.0});
+    std::printf("FACTORS spheres=%zu max|H - Hnum|=%.1e goal_err=(%.1e, %.1e, %.1e)\n", e0.size(), worst, ge[0], ge[1], ge[2]);
+    if (worst > 1e-5 || std::fabs(ge[0]) + std::fabs(ge[1]) + std::fabs(ge[2]) > 1e-12) return 6;
+    // mobile manipulator through the same planner entry point
+    Pose2MobileArmModel mmodel(Pose2MobileArm(arm, Pose3::Translation(0.1, 0.0, 0.0)),
+                               {BodySphere(0, 0.3, {0.0, 0.0, 0.0}), BodySphere(1, 0.1, {-0.5, 0.0, 0.0}), BodySphere(2, 0.1, {-0.5, 0.0, 0.0})});
+    TrajOptimizerSetting msetting(5);
+    msetting.set_total_step(10);
+    msetting.set_total_time(2.0);
+    msetting.set_obs_check_inter(1);
+    msetting.setLM();
+    const Vector ms{-2.0, -2.0, 0.0, 0.0, 0.0}, me{-1.0, -2.2, 0.3, 0.5, 0.2}, mz(5, 0.0);
+    int miters = 0;
+    const Trajectory mout = BatchTrajOptimizePose2MobileArm2D(mmodel, sdf, ms, mz, me, mz, initArmTrajStraightLine(ms, me, 10),
+                                                              msetting, &miters);
+    std::printf("MOBILE iterations=%d x_10=(%.3f, %.3f, %.3f)\n", miters, mout.x(10)[0], mout.x(10)[1], mout.x(10)[2]);
+    if (std::fabs(mout.x(10)[0] - me[0]) > 1e-2) return 7;
     // replanner: batch answer as initial values, fix state 3 where it is, move the goal, two updates
     ISAM2TrajOptimizer2DArm isam(model, sdf, setting);
     isam.initFactorGraph(start, zero, end, zero);
