@@ -221,8 +221,10 @@ int gpmp2mi_plan_set_problem_dev(gpmp2mi_plan* p, const double* start_conf, cons
                                  const double* end_conf, const double* end_vel, const double* init,
                                  void* stream);
 
-/* Run gpmp2::optimize on every trajectory of the batch (device resident, asynchronous on
- * `stream`; pass NULL for the default stream).  Re-running after set_problem re-optimises. */
+/* Run gpmp2::optimize on every trajectory of the batch.  All work is enqueued on `stream`
+ * (hipStream_t; NULL = the default stream) and stays on the device; the host only follows the
+ * per-pass active counts (pinned flags, no copies) to know when to stop enqueueing passes, and the call
+ * returns once the stream has drained.  Re-running after set_problem re-optimises. */
 int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream);
 
 /* Results.  traj [B][N+1][2D]; iters [B] (GTSAM `iterations()`); final_error [B] (graph error of
