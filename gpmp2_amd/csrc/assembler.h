@@ -73,13 +73,15 @@ struct Assembler {
   // are issued before the first LDS store so the wavefront pays one memory latency, not one per
   // 64 values; NLD bounds the per-lane load count (checked on the host).
   static constexpr int NLD = (D <= 7) ? 10 : 16;
-  __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1) const {
+  // count = 1 stages interval iv only (kernels whose wavefronts share their slots)
+  __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1, int count = 2) const {
     const int I = P.I;
     const double* rb = rec + (size_t)b * P.REC * P.Ppad;
     const double* gb = gpu + (size_t)b * P.GPREC * P.Npad;
     double val[2][NLD];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
+      if (w >= count) break;
       const int ivw = iv + w;
       const int npt = (ivw == 0) ? 1 : I + 1;
       const int nv = P.REC * npt;
@@ -103,6 +105,7 @@ struct Assembler {
     }
 #pragma unroll
     for (int w = 0; w < 2; w++) {
+      if (w >= count) break;
       const Slot& s = w ? s1 : s0;
       const int ivw = iv + w;
       const int npt = (ivw == 0) ? 1 : I + 1;

@@ -164,15 +164,16 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* _
   const bool live = i <= N;             // the last group may be partly empty
   const int ic = live ? i : N;          // idle wavefronts shadow block N up to the barriers
   extern __shared__ __attribute__((aligned(16))) double asm_smem[];
-  const int slot_dbl = 2 * Asm::slot_doubles(P.I, P.REC, P.GPREC);
-  double* my_smem = asm_smem + (size_t)wv * slot_dbl;
-  double* xch = asm_smem + (size_t)ASM_WAVES * slot_dbl;   // [2 odd blocks][Wl, Wr] tiles for level 2
+  // the 4 blocks of the group need the 5 intervals 4q .. 4q+4; every interval is staged once, into a slot all
+  // wavefronts can read: wavefront wv stages interval 4q + wv (the last one also 4q + 4) and then uses slots
+  // wv (interval i) and wv + 1 (interval i + 1)
+  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.REC, P.GPREC);   // [2 odd blocks][Wl, Wr]
   const double* rec = rec_of(pb, pb.which[b], bufsel);
   const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
   G2_ASTAMP(0);
-  const typename Asm::Slot slot0 = as.make_slot(my_smem, 0), slot1 = as.make_slot(my_smem, 1);
-  as.stage2(ic, slot0, slot1);
+  const typename Asm::Slot slot0 = as.make_slot(asm_smem, wv), slot1 = as.make_slot(asm_smem, wv + 1);
+  as.stage2(i, slot0, slot1, wv == ASM_WAVES - 1 ? 2 : 1);
   __syncthreads();
   G2_ASTAMP(1);
   const bool odd = (i & 1) != 0;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* _
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st) {
   const dim3 grid(hp.B * ((hp.N + ASM_WAVES) / ASM_WAVES)), block(64 * ASM_WAVES);
-  const size_t shmem = (ASM_WAVES * 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) + 4 * TILE_DBL) * sizeof(double);
+  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) + 4 * TILE_DBL) * sizeof(double);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
   case DD:                                                                                              \
