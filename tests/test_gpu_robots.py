@@ -237,3 +237,31 @@ def test_wide_dense_fallback_agrees(engine, oracle, monkeypatch):
         assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
         np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
     np.testing.assert_allclose(tiles["traj"], dense["traj"], atol=1e-7)
+
+
+def test_wide_robot_replanning(engine, oracle):
+    """fix_state / change_goal / update on a 10-dof mobile manipulator (2x2-tile blocks carry the extra priors too)"""
+    model = _wide_models()["mobile WAM (dof 10)"]
+    p = _tree_problem(model, N=10, inter=2, opt="GN")
+    D = model.dof()
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    pl = engine.plan(r, s, p.setting, 1)
+    pl.set_problem(p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
+    pl.optimize()
+    first = pl.result()["traj"]
+    goal2 = p.end_conf[0].copy()
+    goal2[:2] += [0.3, -0.2]
+    goal2[3:] *= 0.5
+    pl.fix_state(0, 4, first[0, 4, :D], first[0, 4, D:])
+    pl.change_goal(0, goal2, np.zeros(D))
+    pl.update(iterations=2)
+    got = pl.result()
+    st = p.setting
+    st.setGaussNewton()
+    st.fixed_iterations = 2
+    w = 1.0 / st.conf_prior_sigma ** 2
+    priors = [[dict(state=4, conf=first[0, 4, :D], Wc=w * np.eye(D), vel=first[0, 4, D:], Wv=w * np.eye(D))]]
+    ref = oracle.batch_optimize_xp(ro, so, st, p.start_conf, p.start_vel, goal2[None], p.end_vel, first, priors, [1])
+    np.testing.assert_allclose(got["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(got["traj"][0, 4], first[0, 4], atol=1e-3)
