@@ -16,7 +16,8 @@ from .factors import (GaussianPriorWorkspaceOrientationArm, GaussianPriorWorkspa
                       GaussianProcessPriorPose2Vector, GoalFactorArm, JointLimitFactorVector,
                       ObstaclePlanarSDFFactorArm, ObstaclePlanarSDFFactorGPArm, ObstaclePlanarSDFFactorGPPointRobot,
                       ObstaclePlanarSDFFactorPointRobot, ObstacleSDFFactorArm, ObstacleSDFFactorGPArm,
-                      SelfCollisionArm, VelocityLimitFactorVector)
+                      SelfCollisionArm, VehicleDynamicsFactorPose2, VehicleDynamicsFactorPose2Vector,
+                      VehicleDynamicsFactorVector, VelocityLimitFactorVector)
 from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2MobileArm,  # noqa: F401
                       BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,

@@ -736,6 +736,25 @@ int gpmp2mi_interpolate_traj(int D, int lie, const double* Qc, double dt, int in
   return GPMP2MI_OK;
 }
 
+int gpmp2mi_vehicle_dynamics_factor(int D, int lie, int M, const double* conf, const double* vel, double* err, double* Hp,
+                                    double* Hv) {
+  G2_CHECK(conf && vel && err && M >= 0 && D >= 3, GPMP2MI_ERR_INVALID, "null argument or dof < 3");
+  if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
+  DevBuf<double> dc, dv, de, dp, dh;
+  G2_TRY(dc.upload(conf, (size_t)M * D));
+  G2_TRY(dv.upload(vel, (size_t)M * D));
+  G2_TRY(de.alloc(M));
+  if (Hp) G2_TRY(dp.alloc((size_t)M * D));
+  if (Hv) G2_TRY(dh.alloc((size_t)M * D));
+  G2_TRY(launch_vehicle_dynamics(D, lie, M, dc.p, dv.p, de.p, dp.p, dh.p, nullptr));
+  G2_HIP(hipDeviceSynchronize());
+  G2_TRY(de.download(err));
+  G2_TRY(dp.download(Hp));
+  G2_TRY(dh.download(Hv));
+  return GPMP2MI_OK;
+}
+
 int gpmp2mi_joint_limit_factor(int D, const double* down, const double* up, const double* th, int M,
                                const double* x, double* err, double* Hd) {
   G2_CHECK(down && up && th && x && err && M >= 0 && D > 0, GPMP2MI_ERR_INVALID, "null argument");

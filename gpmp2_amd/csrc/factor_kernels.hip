@@ -635,6 +635,29 @@ __global__ void k_self_collision(int n, int S, int D, int M, const double* __res
   }
 }
 
+// simple2DVehicleDynamicsPose2 / ...Vector3  dynamics/VehicleDynamics.h:19-40
+__global__ void k_vehicle_dynamics(int D, int lie, int M, const double* __restrict__ conf, const double* __restrict__ vel,
+                                   double* __restrict__ err, double* __restrict__ Hp, double* __restrict__ Hv) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const double* p = conf + (size_t)m * D;
+  const double* v = vel + (size_t)m * D;
+  double hp[3] = {0.0, 0.0, 0.0}, hv[3] = {0.0, 1.0, 0.0}, e = v[1];
+  if (!lie) {
+    double sn, cs;
+    sincos(p[2], &sn, &cs);
+    hp[2] = -(v[1] * sn + v[0] * cs);
+    hv[0] = -sn;
+    hv[1] = cs;
+    e = v[1] * cs - v[0] * sn;
+  }
+  err[m] = e;
+  for (int k = 0; k < D; k++) {
+    if (Hp) Hp[(size_t)m * D + k] = (k < 3) ? hp[k] : 0.0;
+    if (Hv) Hv[(size_t)m * D + k] = (k < 3) ? hv[k] : 0.0;
+  }
+}
+
 // JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
 __global__ void k_joint_limit(int D, const double* __restrict__ down, const double* __restrict__ up,
                               const double* __restrict__ th, int M, const double* __restrict__ x,
@@ -716,6 +739,13 @@ int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N,
 #undef G2_IT
     default: set_error("dof must be 1..10"); return GPMP2MI_ERR_UNSUPPORTED;
   }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
+int launch_vehicle_dynamics(int D, int lie, int M, const double* conf, const double* vel, double* err, double* Hp,
+                            double* Hv, hipStream_t st) {
+  k_vehicle_dynamics<<<G2_GRID(M)>>>(D, lie, M, conf, vel, err, Hp, Hv);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

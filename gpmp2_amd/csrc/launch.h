@@ -30,6 +30,8 @@ int launch_gp_prior_lie(int D, double dt, int M, const double* c1, const double*
                         hipStream_t st);
 int launch_interpolate_traj(int D, bool lie, double dt, int inter, int B, int N, int start, int Mo,
                             const double* traj, double* out, hipStream_t st);
+int launch_vehicle_dynamics(int D, int lie, int M, const double* conf, const double* vel, double* err, double* Hp,
+                            double* Hv, hipStream_t st);
 int launch_workspace_prior(int mode, int joint, int L, int D, int M, const double* des, const double* poses,
                            const double* Jp, double* err, double* H, hipStream_t st);
 int launch_self_collision(int n, int S, int D, int M, const double* data, const double* radius, const double* c,

@@ -233,6 +233,15 @@ class Engine:
         self._ck(self.lib.gpmp2mi_self_collision_factor(robot.ptr, n, dptr(d), M, dptr(q), dptr(err), dptr(H)))
         return err, H
 
+    def vehicle_dynamics_factor(self, lie, conf, vel):
+        """sliding velocity of an SE(2) base -> err [M], Hp [M][D], Hv [M][D]"""
+        q, v = f64(conf), f64(vel)
+        q, v = q.reshape(-1, q.shape[-1]), v.reshape(-1, v.shape[-1])
+        M, D = q.shape
+        err, Hp, Hv = np.zeros(M), np.zeros((M, D)), np.zeros((M, D))
+        self._ck(self.lib.gpmp2mi_vehicle_dynamics_factor(D, int(lie), M, dptr(q), dptr(v), dptr(err), dptr(Hp), dptr(Hv)))
+        return err, Hp, Hv
+
     def joint_limit_factor(self, down, up, thresh, x):
         down, up, thresh = f64(down).reshape(-1), f64(up).reshape(-1), f64(thresh).reshape(-1)
         D = down.size

@@ -198,3 +198,25 @@ class SelfCollisionArm(_Keyed):
     def evaluateError(self, conf, jacobians=False):
         err, H = _eng().self_collision_factor(_robot_handle(self.robot_), self.data_, _one(conf))
         return (err[0], H[0]) if jacobians else err[0]
+
+
+class VehicleDynamicsFactorPose2Vector(_Keyed):
+    """gpmp2::VehicleDynamicsFactorPose2Vector  gpmp2/dynamics/VehicleDynamicsFactorPose2Vector.h:24-100 (Lie form: the
+    body-frame lateral velocity v(1)); VehicleDynamicsFactorPose2 is the 3-dof case of the same"""
+    _lie = True
+
+    def __init__(self, poseKey, velKey, cost_sigma):
+        self._keys, self.cost_sigma_ = (poseKey, velKey), cost_sigma
+
+    def evaluateError(self, conf, vel, jacobians=False):
+        err, Hp, Hv = _eng().vehicle_dynamics_factor(self._lie, _one(conf), _one(vel))
+        return (err, Hp[0][None], Hv[0][None]) if jacobians else err
+
+
+VehicleDynamicsFactorPose2 = VehicleDynamicsFactorPose2Vector
+
+
+class VehicleDynamicsFactorVector(VehicleDynamicsFactorPose2Vector):
+    """gpmp2::VehicleDynamicsFactorVector  gpmp2/dynamics/VehicleDynamicsFactorVector.h:24-98 (vector form:
+    v_y cos(theta) - v_x sin(theta) with world-frame velocities)"""
+    _lie = False

@@ -366,6 +366,13 @@ int gpmp2mi_goal_factor_arm(const gpmp2mi_robot* r, const double dest_point[3], 
 int gpmp2mi_self_collision_factor(const gpmp2mi_robot* r, int n_pairs, const double* data, int M,
                                   const double* conf, double* err, double* H);
 
+/* VehicleDynamicsFactorPose2 / Pose2Vector (lie = 1) and VehicleDynamicsFactorVector (lie = 0)
+ * dynamics/VehicleDynamics.h:19-40, dynamics/VehicleDynamicsFactorPose2Vector.h:55-78,
+ * dynamics/VehicleDynamicsFactorVector.h:53-78: sliding velocity of an SE(2) base.  conf, vel [M][D] with
+ * D >= 3 (the first three coordinates are x, y, theta).  -> err [M], Hp [M][D], Hv [M][D] (may be NULL). */
+int gpmp2mi_vehicle_dynamics_factor(int dof, int lie, int M, const double* conf, const double* vel,
+                                    double* err, double* Hp, double* Hv);
+
 /* JointLimitFactorVector / VelocityLimitFactorVector ::evaluateError
  * kinematics/JointLimitFactorVector.h:62-79, kinematics/VelocityLimitFactorVector.h:62-79.
  * x [M][D] -> err [M][D], Hdiag [M][D] (the diagonal of the Jacobian). */

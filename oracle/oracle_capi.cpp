@@ -1,6 +1,7 @@
 // oracle_capi.cpp -- extern "C" surface of the CPU oracle (TEST INFRASTRUCTURE ONLY).
 // Mirrors include/gpmp2mi.h one-to-one with the prefix `orc_` so that parity tests call the
 // oracle and the HIP library with identical arguments.  Never linked into the product.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
@@ -175,6 +176,28 @@ int orc_self_collision_factor(const void* r, int n_pairs, const double* data, in
   for (int m = 0; m < M; m++)
     self_collision_factor(R, n_pairs, data, conf + (size_t)m * R.dof, err + (size_t)m * n_pairs,
                           H ? H + (size_t)m * n_pairs * R.dof : nullptr);
+  return 0;
+}
+
+// simple2DVehicleDynamicsPose2 / ...Vector3  dynamics/VehicleDynamics.h:19-40
+int orc_vehicle_dynamics_factor(int D, int lie, int M, const double* conf, const double* vel, double* err, double* Hp,
+                                double* Hv) {
+  for (int m = 0; m < M; m++) {
+    const double* p = conf + (size_t)m * D;
+    const double* v = vel + (size_t)m * D;
+    double hp[3] = {0, 0, 0}, hv[3] = {0, 1, 0}, e = v[1];
+    if (!lie) {
+      hp[2] = -(v[1] * std::sin(p[2]) + v[0] * std::cos(p[2]));
+      hv[0] = -std::sin(p[2]);
+      hv[1] = std::cos(p[2]);
+      e = v[1] * std::cos(p[2]) - v[0] * std::sin(p[2]);
+    }
+    err[m] = e;
+    for (int k = 0; k < D; k++) {
+      if (Hp) Hp[(size_t)m * D + k] = k < 3 ? hp[k] : 0.0;
+      if (Hv) Hv[(size_t)m * D + k] = k < 3 ? hv[k] : 0.0;
+    }
+  }
   return 0;
 }
 

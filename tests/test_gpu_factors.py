@@ -341,3 +341,16 @@ def test_goal_and_workspace_priors_gpu(engine, oracle, golden):
                 np.testing.assert_allclose(a[1], b[1], atol=1e-10)
     with pytest.raises(g.engine.Gpmp2miError):
         engine.workspace_prior_factor(r, 2, 7, des, q)
+
+
+def test_vehicle_dynamics_factor_gpu(engine, oracle, golden):
+    d = golden["vehicle_dynamics"]                             # testVehicleDynamics.cpp:23-169
+    for lie, cases in ((True, d["lie_cases"]), (False, d["vector_cases"])):
+        for c in cases:
+            err, _, _ = engine.vehicle_dynamics_factor(lie, vec(c["p"]), vec(c["v"]))
+            if c["expected"] is not None:
+                assert abs(err[0] - c["expected"]) <= d["tol"]
+        rng = np.random.default_rng(8)
+        q, v = rng.normal(size=(30, 5)), rng.normal(size=(30, 5))
+        for x, y in zip(engine.vehicle_dynamics_factor(lie, q, v), oracle.vehicle_dynamics_factor(lie, q, v)):
+            np.testing.assert_allclose(x, y, atol=1e-13)

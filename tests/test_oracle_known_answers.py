@@ -584,3 +584,19 @@ def test_vetlin_reverse_linact(oracle, golden):
     poses, _ = oracle.forward_kinematics(oracle.robot(model), q)
     assert abs(poses[0, 1][2, 3] + 1.5) < 1e-12 and abs(poses[0, 2][2, 3] - 0.5) < 1e-12   # torso moved down
     _check_tree_fk(oracle, model, q)
+
+
+def test_vehicle_dynamics_factor_both_forms(oracle, golden):
+    d = golden["vehicle_dynamics"]                             # testVehicleDynamics.cpp:23-169
+    for lie, cases in ((True, d["lie_cases"]), (False, d["vector_cases"])):
+        for c in cases:
+            p, v = vec(c["p"]), vec(c["v"])
+            err, Hp, Hv = oracle.vehicle_dynamics_factor(lie, p, v)
+            if c["expected"] is not None:
+                assert abs(err[0] - c["expected"]) <= d["tol"]
+            f = lambda pp, vv: oracle.vehicle_dynamics_factor(lie, pp, vv)[0][0]
+            np.testing.assert_allclose(Hv[0], numeric_jacobian(lambda x: f(p, x), v, 1e-6), atol=1e-6)
+            if not lie:   # the Lie form's Hp is zero by definition (body-frame velocity)
+                np.testing.assert_allclose(Hp[0], numeric_jacobian(lambda x: f(x, v), p, 1e-6), atol=1e-6)
+            else:
+                assert not Hp.any()
