@@ -18,8 +18,11 @@ from .factors import (GaussianPriorWorkspaceOrientationArm, GaussianPriorWorkspa
                       ObstaclePlanarSDFFactorPointRobot, ObstacleSDFFactorArm, ObstacleSDFFactorGPArm,
                       SelfCollisionArm, VehicleDynamicsFactorPose2, VehicleDynamicsFactorPose2Vector,
                       VehicleDynamicsFactorVector, VelocityLimitFactorVector)
-from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2MobileArm,  # noqa: F401
-                      BatchTrajOptimizePose2MobileArm2D, CollisionCost2DArm, CollisionCost3DArm,
+from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajOptimizePose2Mobile2Arms,  # noqa: F401
+                      BatchTrajOptimizePose2MobileArm, BatchTrajOptimizePose2MobileArm2D,
+                      BatchTrajOptimizePose2MobileVetLin2Arms, BatchTrajOptimizePose2MobileVetLinArm,
+                      CollisionCostPose2Mobile2Arms, CollisionCostPose2MobileVetLin2Arms,
+                      CollisionCostPose2MobileVetLinArm, ISAM2TrajOptimizerPose2MobileVetLin2Arms, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,
                       ISAM2TrajOptimizer3DArm, ISAM2TrajOptimizerPose2MobileArm, ISAM2TrajOptimizerPose2MobileArm2D,
                       PlanarSDF, SDFQueryOutOfRange, SignedDistanceField, readSDFvolfile, signedDistanceField2D,

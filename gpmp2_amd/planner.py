@@ -175,6 +175,9 @@ BatchTrajOptimize2DArm = _batch
 BatchTrajOptimize3DArm = _batch
 BatchTrajOptimizePose2MobileArm2D = _batch
 BatchTrajOptimizePose2MobileArm = _batch
+BatchTrajOptimizePose2Mobile2Arms = _batch
+BatchTrajOptimizePose2MobileVetLinArm = _batch
+BatchTrajOptimizePose2MobileVetLin2Arms = _batch
 BatchTrajOptimizePointRobot2D = _batch       # the PointRobot graphs of the matlab examples
 
 
@@ -190,6 +193,9 @@ CollisionCostPose2MobileBase2D = _collision_cost
 CollisionCostPose2MobileBase = _collision_cost
 CollisionCostPose2MobileArm2D = _collision_cost
 CollisionCostPose2MobileArm = _collision_cost
+CollisionCostPose2Mobile2Arms = _collision_cost
+CollisionCostPose2MobileVetLinArm = _collision_cost
+CollisionCostPose2MobileVetLin2Arms = _collision_cost
 
 
 class _ISAM2TrajOptimizer:
@@ -257,3 +263,7 @@ class ISAM2TrajOptimizerPose2MobileArm2D(_ISAM2TrajOptimizer):
 
 class ISAM2TrajOptimizerPose2MobileArm(_ISAM2TrajOptimizer):
     """gpmp2/planner/ISAM2TrajOptimizer.h:165-170"""
+
+
+class ISAM2TrajOptimizerPose2MobileVetLin2Arms(_ISAM2TrajOptimizer):
+    """gpmp2/planner/ISAM2TrajOptimizer.h:173-178"""
