@@ -508,3 +508,28 @@ def test_edge_sizes_empty_long_and_many_spheres(engine, oracle):
     far = g.ArmModel(g.Arm(7, wam.fk_model().a, wam.fk_model().alpha, wam.fk_model().d, g.pose3(t=(50.0, 0.0, 0.0))), sph[:8])
     a, b = engine.obstacle_factor(engine.robot(far), s, 0.2, q), oracle.obstacle_factor(oracle.robot(far), so, 0.2, q)
     assert not a[0].any() and not a[1].any() and not b[0].any()
+
+
+def test_two_plans_from_two_host_threads(engine, oracle):
+    """independent plans driven concurrently from two host threads give the same answers as one after the other
+    (per-plan device state, thread-local error state, no shared scratch)"""
+    import threading
+    pa = problems.wam_restarts(B=6, total_step=20, obs_check_inter=3, opt="GN", sdf="40")
+    pbm = problems.wam_restarts(B=4, total_step=14, obs_check_inter=1, opt="LM", sdf="40")
+    out = {}
+
+    def run(key, p):
+        r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+        pl = engine.plan(r, s, p.setting, p.B)
+        pl.set_problem(*_args(p), p.init)
+        for _ in range(5):
+            pl.optimize()
+        out[key] = pl.result()
+
+    run("a_seq", pa)
+    run("b_seq", pbm)
+    ta, tb = threading.Thread(target=run, args=("a_par", pa)), threading.Thread(target=run, args=("b_par", pbm))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    for k in ("a", "b"):
+        np.testing.assert_array_equal(out[k + "_seq"]["iters"], out[k + "_par"]["iters"])
+        np.testing.assert_array_equal(out[k + "_seq"]["traj"], out[k + "_par"]["traj"])
