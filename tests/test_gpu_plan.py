@@ -533,3 +533,29 @@ def test_two_plans_from_two_host_threads(engine, oracle):
     for k in ("a", "b"):
         np.testing.assert_array_equal(out[k + "_seq"]["iters"], out[k + "_par"]["iters"])
         np.testing.assert_array_equal(out[k + "_seq"]["traj"], out[k + "_par"]["traj"])
+
+
+def test_reference_small_graph_solves_on_gpu(engine, golden):
+    """the only solve-level expectations the reference's own tests hold
+    (gp/tests/testGaussianProcessPriorLinear.cpp:140-202, kinematics/tests/testJointLimitFactorVector.cpp:67-158),
+    through the planner on the GPU"""
+    import gpmp2_amd as g
+    from test_oracle_solve import gp_prior_graph_problem, joint_limit_graph_problem
+    field = np.full((3, 3, 3), 10.0)
+    s = engine.sdf([-1, -1, -1], 1.0, field)
+
+    def arm(dof):
+        return engine.robot(g.ArmModel(g.Arm(dof, [1.0] * dof, [0.0] * dof, [0.0] * dof), []))
+
+    st, sc, sv, ec, ev, init, o = gp_prior_graph_problem(golden)
+    res = engine.batch_optimize(arm(3), s, st, sc, sv, ec, ev, init)
+    np.testing.assert_allclose(res["traj"][0, 0, :3], o["p1"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 1, :3], o["p2"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 0, 3:], o["v1"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 1, 3:], o["v2"], atol=1e-6)
+    assert res["final_error"][0] < 1e-6
+    r2 = arm(2)
+    for conf, want in (([0.0, 0.0], [0.0, 0.0]), ([-10.0, -10.0], [-3.0, -8.0]), ([10.0, 10.0], [3.0, 8.0])):
+        st, sc, sv, ec, ev, init = joint_limit_graph_problem(golden, conf)
+        res = engine.batch_optimize(r2, s, st, sc, sv, ec, ev, init)
+        np.testing.assert_allclose(res["traj"][0, :, :2], [want, want], atol=1e-6)

@@ -5,6 +5,7 @@ Jacobian, and the optimizer loop against its own invariants."""
 import numpy as np
 import pytest
 
+import gpmp2_amd as g
 from gpmp2_amd import problems
 
 
@@ -77,3 +78,71 @@ def test_collision_cost_uses_zero_epsilon(oracle, small_wam):
     c = oracle.collision_cost(r, s, 12, p.init)
     err, _ = oracle.obstacle_factor(r, s, 0.0, p.init[:, :, :7].reshape(-1, 7))
     np.testing.assert_allclose(c, err.reshape(p.B, -1).sum(axis=1), rtol=1e-12)
+
+
+# ------------------------------------------------------------------ the reference's own small-graph solves
+def _no_sphere_arm(dof):
+    return g.ArmModel(g.Arm(dof, [1.0] * dof, [0.0] * dof, [0.0] * dof), [])
+
+
+def gp_prior_graph_problem(golden):
+    """testGaussianProcessPriorLinear.cpp:140-202: pose priors (sigma 1e-3) on both states + one GP prior, noisy
+    initial values; Gauss-Newton must recover v1 = v2 = (1, 0, 0).  The planner always carries velocity priors on
+    the end states; sigma 1e6 makes them vanish (weight 1e-12 against 1e5 of the GP prior)."""
+    from gpmp2_amd.settings import TrajOptimizerSetting
+    d = golden["gp_prior_linear"]
+    o = d["optimization"]
+    st = TrajOptimizerSetting(3)
+    st.set_total_step(1)
+    st.set_total_time(d["delta_t"])
+    st.set_obs_check_inter(0)
+    st.set_conf_prior_model(o["prior_sigma"])
+    st.set_vel_prior_model(1e6)
+    st.set_Qc_model(d["Qc_scale"] * np.eye(3))
+    st.setGaussNewton()
+    st.set_rel_thresh(1e-12)
+    init = np.array([[o["p1init"] + o["v1init"], o["p2init"] + o["v2init"]]], dtype=float)
+    z = np.zeros((1, 3))
+    return st, np.array([o["p1"]], dtype=float), z, np.array([o["p2"]], dtype=float), z.copy(), init, o
+
+
+def joint_limit_graph_problem(golden, conf):
+    """testJointLimitFactorVector.cpp:67-158: limit factor (sigma 1e-3) + weak prior (sigma 1000) on one
+    configuration; here on both states of a one-interval plan, which the GP prior leaves at rest."""
+    from gpmp2_amd.settings import TrajOptimizerSetting
+    d = golden["joint_limit"]
+    st = TrajOptimizerSetting(2)
+    st.set_total_step(1)
+    st.set_total_time(1.0)
+    st.set_obs_check_inter(0)
+    st.set_conf_prior_model(1000.0)
+    st.set_vel_prior_model(1.0)
+    st.set_Qc_model(np.eye(2))
+    st.set_flag_pos_limit(True)
+    st.set_joint_pos_limits_down(d["down"])
+    st.set_joint_pos_limits_up(d["up"])
+    st.set_pos_limit_thresh(d["thresh"])
+    st.set_pos_limit_model([0.001, 0.001])
+    st.setGaussNewton()
+    st.set_rel_thresh(1e-12)
+    c = np.array([conf], dtype=float)
+    z = np.zeros((1, 2))
+    init = np.concatenate([c, z], axis=1)[:, None, :].repeat(2, axis=1)
+    return st, c, z, c.copy(), z.copy(), init
+
+
+def test_reference_small_graph_solves(oracle, golden):
+    field = np.full((3, 3, 3), 10.0)
+    st, sc, sv, ec, ev, init, o = gp_prior_graph_problem(golden)
+    r, s = oracle.robot(_no_sphere_arm(3)), oracle.sdf([-1, -1, -1], 1.0, field)
+    res = oracle.batch_optimize(r, s, st, sc, sv, ec, ev, init)
+    np.testing.assert_allclose(res["traj"][0, 0, :3], o["p1"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 1, :3], o["p2"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 0, 3:], o["v1"], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, 1, 3:], o["v2"], atol=1e-6)
+    assert res["final_error"][0] < 1e-6
+    r2 = oracle.robot(_no_sphere_arm(2))
+    for conf, want in (([0.0, 0.0], [0.0, 0.0]), ([-10.0, -10.0], [-3.0, -8.0]), ([10.0, 10.0], [3.0, 8.0])):
+        st, sc, sv, ec, ev, init = joint_limit_graph_problem(golden, conf)
+        res = oracle.batch_optimize(r2, s, st, sc, sv, ec, ev, init)
+        np.testing.assert_allclose(res["traj"][0, :, :2], [want, want], atol=1e-6)
