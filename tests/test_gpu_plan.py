@@ -540,7 +540,7 @@ def test_reference_small_graph_solves_on_gpu(engine, golden):
     (gp/tests/testGaussianProcessPriorLinear.cpp:140-202, kinematics/tests/testJointLimitFactorVector.cpp:67-158),
     through the planner on the GPU"""
     import gpmp2_amd as g
-    from test_oracle_solve import gp_prior_graph_problem, joint_limit_graph_problem
+    from test_oracle_solve import gp_prior_graph_problem, joint_limit_graph_problem, lie_gp_prior_graph_problem
     field = np.full((3, 3, 3), 10.0)
     s = engine.sdf([-1, -1, -1], 1.0, field)
 
@@ -553,6 +553,11 @@ def test_reference_small_graph_solves_on_gpu(engine, golden):
     np.testing.assert_allclose(res["traj"][0, 1, :3], o["p2"], atol=1e-6)
     np.testing.assert_allclose(res["traj"][0, 0, 3:], o["v1"], atol=1e-6)
     np.testing.assert_allclose(res["traj"][0, 1, 3:], o["v2"], atol=1e-6)
+    assert res["final_error"][0] < 1e-6
+    model, st, sc, sv, ec, ev, init, v1 = lie_gp_prior_graph_problem()   # testGaussianProcessPriorPose2Vector.cpp:147-200
+    res = engine.batch_optimize(engine.robot(model), s, st, sc, sv, ec, ev, init)
+    np.testing.assert_allclose(res["traj"][0, :, :6], [sc[0], ec[0]], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, :, 6:], [v1, v1], atol=1e-6)
     assert res["final_error"][0] < 1e-6
     r2 = arm(2)
     for conf, want in (([0.0, 0.0], [0.0, 0.0]), ([-10.0, -10.0], [-3.0, -8.0]), ([10.0, 10.0], [3.0, 8.0])):

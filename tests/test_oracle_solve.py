@@ -131,6 +131,26 @@ def joint_limit_graph_problem(golden, conf):
     return st, c, z, c.copy(), z.copy(), init
 
 
+def lie_gp_prior_graph_problem():
+    """testGaussianProcessPriorPose2Vector.cpp:147-200: the same graph on Pose2Vector states (dof 6)"""
+    from gpmp2_amd.settings import TrajOptimizerSetting
+    st = TrajOptimizerSetting(6)
+    st.set_total_step(1)
+    st.set_total_time(0.1)
+    st.set_obs_check_inter(0)
+    st.set_conf_prior_model(0.001)
+    st.set_vel_prior_model(1e6)
+    st.set_Qc_model(0.01 * np.eye(6))
+    st.setGaussNewton()
+    st.set_rel_thresh(1e-12)
+    pose1, pose2 = np.zeros(6), np.array([0.1, 0, 0, 0, 0.2, 0])
+    v1, v2rnd = np.array([1.0, 0, 0, 0, 2, 0]), np.array([1.2, 0.3, 0.4, 1.0, 1.0, -1.0])
+    init = np.array([[np.concatenate([pose1, v1]), np.concatenate([pose2, v2rnd])]])
+    z = np.zeros((1, 6))
+    model = g.ArmModel(g.Pose2MobileArm(g.Arm(3, [1.0] * 3, [0.0] * 3, [0.0] * 3)), [])
+    return model, st, pose1[None], z, pose2[None], z.copy(), init, v1
+
+
 def test_reference_small_graph_solves(oracle, golden):
     field = np.full((3, 3, 3), 10.0)
     st, sc, sv, ec, ev, init, o = gp_prior_graph_problem(golden)
@@ -140,6 +160,11 @@ def test_reference_small_graph_solves(oracle, golden):
     np.testing.assert_allclose(res["traj"][0, 1, :3], o["p2"], atol=1e-6)
     np.testing.assert_allclose(res["traj"][0, 0, 3:], o["v1"], atol=1e-6)
     np.testing.assert_allclose(res["traj"][0, 1, 3:], o["v2"], atol=1e-6)
+    assert res["final_error"][0] < 1e-6
+    model, st, sc, sv, ec, ev, init, v1 = lie_gp_prior_graph_problem()
+    res = oracle.batch_optimize(oracle.robot(model), s, st, sc, sv, ec, ev, init)
+    np.testing.assert_allclose(res["traj"][0, :, :6], [sc[0], ec[0]], atol=1e-6)
+    np.testing.assert_allclose(res["traj"][0, :, 6:], [v1, v1], atol=1e-6)
     assert res["final_error"][0] < 1e-6
     r2 = oracle.robot(_no_sphere_arm(2))
     for conf, want in (([0.0, 0.0], [0.0, 0.0]), ([-10.0, -10.0], [-3.0, -8.0]), ([10.0, 10.0], [3.0, 8.0])):
