@@ -22,7 +22,7 @@ from .planner import (BatchTrajOptimize2DArm, BatchTrajOptimize3DArm, BatchTrajO
                       BatchTrajOptimizePose2MobileArm, BatchTrajOptimizePose2MobileArm2D,
                       BatchTrajOptimizePose2MobileVetLin2Arms, BatchTrajOptimizePose2MobileVetLinArm,
                       CollisionCostPose2Mobile2Arms, CollisionCostPose2MobileVetLin2Arms,
-                      CollisionCostPose2MobileVetLinArm, ISAM2TrajOptimizerPose2MobileVetLin2Arms, CollisionCost2DArm, CollisionCost3DArm,
+                      CollisionCostPose2MobileBase, CollisionCostPose2MobileBase2D, CollisionCostPose2MobileVetLinArm, ISAM2TrajOptimizerPose2MobileVetLin2Arms, CollisionCost2DArm, CollisionCost3DArm,
                       CollisionCostPose2MobileArm, CollisionCostPose2MobileArm2D, ISAM2TrajOptimizer2DArm,
                       ISAM2TrajOptimizer3DArm, ISAM2TrajOptimizerPose2MobileArm, ISAM2TrajOptimizerPose2MobileArm2D,
                       PlanarSDF, SDFQueryOutOfRange, SignedDistanceField, readSDFvolfile, signedDistanceField2D,
