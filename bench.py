@@ -93,9 +93,14 @@ def main():
     import torch
     import torch.distributed as dist
 
+    # GPMP2MI_BENCH_REHEARSAL=1: exercise the N > 1 control flow on a ONE-GPU box (all ranks on device 0, gloo
+    # collectives on host copies).  Only for checking the multi-rank code path; its numbers mean nothing.
+    rehearsal = os.environ.get("GPMP2MI_BENCH_REHEARSAL") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -133,7 +138,8 @@ def main():
         if world > 1:     # final gather of the results: the only collective on the path
             eng._ck(eng.lib.gpmp2mi_plan_get_result_dev(plan.h.ptr, C.c_void_p(out_traj.data_ptr()), None, None,
                                                         None, C.c_void_p(stream)))
-            gathered[...] = sharding.gather_results(out_traj, B * world)
+            gathered[...] = (sharding.gather_results(out_traj.cpu(), B * world).to(dev) if rehearsal
+                             else sharding.gather_results(out_traj, B * world))
 
     def fence():
         if world > 1:
@@ -164,7 +170,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     iters, status, ferr = plan.result_counts()
