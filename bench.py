@@ -212,7 +212,12 @@ def main():
                         event_sampled_steps=sampled,
                         kernels={k: dict(avg_ms=v["ms"] / v["launches"], launches_per_step=v["launches"] / sampled)
                                  for k, v in kern.items()})
-        out = dict(metric="trajectories/sec", value=total_traj / dt, unit="trajectories/sec", n_gpus=world,
+        try:
+            baseline_metric = json.load(open(os.path.join(ROOT, "BASELINE.json"))).get("metric")
+        except Exception:
+            baseline_metric = None
+        out = dict(metric="trajectories/sec", baseline_metric=baseline_metric, value=total_traj / dt,
+                   unit="trajectories/sec", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                    config=dict(workload=("WAMFactorGraphExample: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 SDF "
