@@ -10,18 +10,29 @@ already resident in HBM.  One process per GPU (torch.distributed / RCCL); the pa
 trajectory (weak scaling: 64 restarts per GPU, no data-path collective), the only collective is the
 final all-gather of the results, which is inside the timed step.
 
+Launching: `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N
+ranks itself (a child `python -m torch.distributed.run`, never an exec; the parent does not touch the
+GPU), relays rank 0's JSON line and exits with the children's status.  Under an external torchrun
+(WORLD_SIZE set) the process is a rank.
+
 Prints ONE JSON line (see the driver contract): metric trajectories/sec, plus
-  roofline      -- dominant kernel, algorithmic bytes (638 048 B per trajectory-iteration,
-                   SURVEY.md 8d) / its average launch duration measured with HIP events on the launch
-                   stream inside the library, vs the 8 TB/s HBM peak
+  roofline      -- whole Gauss-Newton pass (linearize + assemble + solve + finish), SURVEY.md 8(d)'s
+                   638 048 algorithmic bytes per trajectory-iteration / the summed average launch
+                   durations of the pass's kernels (HIP events on the launch stream, inside the
+                   library) vs the 8 TB/s HBM peak; `path_frac` = the same bytes over the wall time of
+                   the step; `mfma_frac` = SURVEY's 5.5 MFLOP per trajectory-iteration over the wall
+                   time vs the fp64 matrix peak; per-kernel averages next to it
   cpu_baseline  -- the CPU oracle (a port of the reference algorithm; the reference itself needs
-                   GTSAM and cannot be built here) timed on this box's host cores on a bounded sample
+                   GTSAM and cannot be built here) timed on this box's host cores on a bounded
+                   sample: all host threads, and a single thread (what the reference is)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +42,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALGO_BYTES_PER_TRAJ_ITER = 638_048       # SURVEY.md section 8(d) contract figure
+ALGO_FLOP_PER_TRAJ_ITER = 5.5e6          # SURVEY.md section 8(d), structured count
 HBM_PEAK_GBS = 8000.0                    # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6                  # MI355X_MICROARCH.md: fp64 vector = matrix peak
+STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "rolled_back", 3: "not_spd", 4: "already_optimal"}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -45,10 +59,46 @@ def parse():
                     help="restarts = BASELINE config 3 (default, the metric's config); windows = config 4 "
                          "(receding-horizon windows warm-started from the solved trajectory, 3 fixed GN iterations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the LM / Dogleg sub-results")
     ap.add_argument("--cpu-sample", type=int, default=0, help="restarts in the CPU sample (0 = auto)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks as a CHILD torchrun (this process has not
+    initialised the GPU and never execs), relay rank 0's JSON line, return the children's status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout:
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        elif s:
+            print(s, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no JSON line", file=sys.stderr)
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------ CPU side
 def cpu_baseline(p, sample, threads):
     """Times the oracle (tests/oracle.py -> oracle/liboracle.so) on `sample` restarts of the same
     workload.  This is the ONLY place bench.py touches the oracle; it is never the thing measured
@@ -63,39 +113,66 @@ def cpu_baseline(p, sample, threads):
                              p.end_vel[sel], p.init[sel], nthreads=threads)
     dt = time.perf_counter() - t0
     return dict(value=sample / dt, unit="trajectories/sec", cores=threads, kind="port",
-                sample=f"first {sample} of the {p.B} restarts, run to tolerance, {threads} OpenMP threads "
+                sample=f"first {sample} of the {p.B} restarts, run to tolerance, {threads} OpenMP thread(s) "
                        f"over trajectories, {dt:.1f} s wall",
                 seconds=dt, traj_iters_per_sec=float(np.sum(res["iters"] + 1)) / dt), res
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of `kernel_prefix` from the newest committed PMC summary under profiles/
-    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same
-    command, gfx950 correction applied; see profiles/README.md).  None when no summary matches."""
+def parity_vs_oracle(ref, gpu, sample):
+    """iteration counts / status / final error / trajectory of the sampled restarts, GPU vs oracle"""
+    gt, gi, gs, gf = gpu
+    fe_rel = np.abs(gf[:sample] - ref["final_error"]) / np.maximum(np.abs(ref["final_error"]), 1e-300)
+    return dict(iters_match_gpu=bool(np.array_equal(ref["iters"], gi[:sample])),
+                status_match_gpu=bool(np.array_equal(ref["status"], gs[:sample])),
+                traj_max_abs_diff=float(np.max(np.abs(gt[:sample] - ref["traj"]))),
+                final_error_max_rel=float(np.max(fe_rel)),
+                restarts_compared=int(sample))
+
+
+def pmc_traffic():
+    """HBM bytes per launch and kernel from the newest committed PMC summary under profiles/ (rocprofv3
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same command, gfx950
+    correction applied; see profiles/README.md).  A STORED profile, not a live measurement."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    for f in reversed(files):
         try:
             d = json.load(open(f))
         except Exception:
             continue
+        out = {}
         for name, v in d.get("kernels", {}).items():
-            if name.startswith(kernel_prefix):
-                best = (v["hbm_bytes_per_launch_corrected"], os.path.basename(f))
-    return best
+            if name.startswith("k_"):
+                out[name.split("<")[0][2:]] = v["hbm_bytes_per_launch_corrected"]
+        if out:
+            return out, os.path.basename(f)
+    return None, None
 
 
+def status_hist(status):
+    return {STATUS_NAMES.get(int(k), str(int(k))): int(v) for k, v in zip(*np.unique(status, return_counts=True))}
+
+
+# ------------------------------------------------------------------------------------------ a rank
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and not (args.gpus == 1 and world > 1):   # a bare external torchrun may omit --gpus
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per requested GPU", file=sys.stderr)
+        sys.exit(2)
     import torch
     import torch.distributed as dist
 
     # GPMP2MI_BENCH_REHEARSAL=1: exercise the N > 1 control flow on a ONE-GPU box (all ranks on device 0, gloo
     # collectives on host copies).  Only for checking the multi-rank code path; its numbers mean nothing.
     rehearsal = os.environ.get("GPMP2MI_BENCH_REHEARSAL") == "1"
+    if not rehearsal and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks requested but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if rehearsal else "nccl", rank=rank, world_size=world)
@@ -103,10 +180,9 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = "cpu" if rehearsal else dev      # where the collectives' tensors live
 
-    from gpmp2_amd import engine, problems
-
-    from gpmp2_amd import sharding
+    from gpmp2_amd import engine, problems, sharding
 
     B = args.batch
     eng = engine.Engine()
@@ -169,11 +245,20 @@ def main():
                 a["launches"] += v["launches"]
     fence()
     dt = time.perf_counter() - t0
+    iters, status, ferr = plan.result_counts()
+    passes_local = int(np.sum(iters + 1))                 # linearize+solve passes per step on this rank
+    hist_local = np.bincount(status, minlength=8)[:8].astype(np.int64)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    iters, status, ferr = plan.result_counts()
+        cnt = torch.tensor([passes_local] + hist_local.tolist(), dtype=torch.int64, device=cdev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        cnt = cnt.cpu().numpy()
+        passes_all, hist_all = int(cnt[0]), cnt[1:]
+        it_all = sharding.gather_results(torch.from_numpy(iters.astype(np.int64)).to(cdev), B * world).cpu().numpy()
+    else:
+        passes_all, hist_all, it_all = passes_local, hist_local, iters
 
     # the boundary handing over HOST buffers (gpmp2mi_plan_set_problem / get_result): same work plus the
     # PCIe copies, reported next to `value`, never as `value`
@@ -190,32 +275,70 @@ def main():
             plan.result()
         host_rate = B * reps / (time.perf_counter() - th)
         plan.set_problem_dev(*[t.data_ptr() for t in t_in], stream=stream)
+        plan.optimize(stream=stream)
+
+    # LM / Dogleg on the same restarts (the optimizers the reference's WAM scripts use), measured in the same
+    # run OUTSIDE the timed Gauss-Newton region
+    variants = None
+    if world == 1 and args.workload == "restarts" and args.opt == "GN" and not args.no_variants:
+        variants = {}
+        for opt in ("LM", "DOGLEG"):
+            pv = problems.wam_restarts(B=B, opt=opt)
+            plv = eng.plan(r, s, pv.setting, B)
+            plv.set_problem_dev(*[t.data_ptr() for t in t_in], stream=stream)
+            plv.optimize(stream=stream)
+            reps = 3
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(reps):
+                plv.optimize(stream=stream)
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            vi, vs, _ = plv.result_counts()
+            variants[opt.lower()] = dict(value=B * reps / tv, unit="trajectories/sec", ms_per_step=tv / reps * 1e3,
+                                         iters=dict(min=int(vi.min()), median=float(np.median(vi)), max=int(vi.max())),
+                                         status_counts=status_hist(vs))
+            plv.close()
+
+    dump = os.environ.get("GPMP2MI_BENCH_DUMP")     # tests: the gathered batch of the last step, for comparison
+    if dump and rank == 0:                          # against a single-rank solve
+        np.savez(dump, traj=(gathered if world > 1 else torch.from_numpy(plan.result()["traj"])).cpu().numpy(),
+                 iters=it_all)
 
     if rank == 0:
         total_traj = B * world * args.steps
         ms_per_step = dt / args.steps * 1e3
-        passes = int(np.sum(iters + 1))                    # linearize+solve passes per step (this rank)
-        dom = max(kern, key=lambda k: kern[k]["ms"]) if kern else None
         roof = None
-        if dom:
-            launches_per_step = kern[dom]["launches"] / sampled
-            avg_ms = kern[dom]["ms"] / kern[dom]["launches"]
-            units_per_launch = passes / launches_per_step      # trajectory-iterations per launch
-            achieved = ALGO_BYTES_PER_TRAJ_ITER * units_per_launch / (avg_ms * 1e-3) / 1e9
-            tr = pmc_traffic("k_" + dom) if (args.workload == "restarts" and B == 64 and args.opt == "GN") else None
-            roof = dict(bound="hbm", kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=(tr[0] if tr else None),
-                        traffic_source=(tr[1] if tr else None),
-                        algorithmic_bytes_per_launch=ALGO_BYTES_PER_TRAJ_ITER * units_per_launch,
-                        avg_launch_ms=avg_ms, launches_per_step=launches_per_step,
-                        units_per_launch=units_per_launch,
-                        event_sampled_steps=sampled,
-                        kernels={k: dict(avg_ms=v["ms"] / v["launches"], launches_per_step=v["launches"] / sampled)
-                                 for k, v in kern.items()})
+        if kern:
+            per = {k: dict(avg_ms=v["ms"] / v["launches"], launches_per_step=v["launches"] / sampled) for k, v in kern.items()}
+            dom = max(kern, key=lambda k: kern[k]["ms"])
+            launches_per_step = per[dom]["launches_per_step"]          # = passes enqueued per step
+            units_per_launch = passes_local / launches_per_step          # trajectory-iterations per pass (this GPU)
+            pass_ms = sum(v["avg_ms"] * v["launches_per_step"] for v in per.values()) / launches_per_step
+            bytes_per_launch = ALGO_BYTES_PER_TRAJ_ITER * units_per_launch
+            achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
+            path_gbs = ALGO_BYTES_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e9
+            path_tflops = ALGO_FLOP_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e12
+            tr, tr_src = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None)
+            traffic = sum(tr.get(k, 0.0) for k in per) if tr else None
+            roof = dict(bound="hbm", kernel="pass: " + " + ".join(per.keys()), dominant_kernel=dom,
+                        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                        traffic=traffic, traffic_source=(tr_src + " (stored rocprofv3 PMC profile, not live)") if tr else None,
+                        algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_ms=pass_ms,
+                        launches_per_step=launches_per_step, units_per_launch=units_per_launch,
+                        path_achieved=path_gbs, path_frac=path_gbs / HBM_PEAK_GBS,
+                        mfma_achieved_tflops=path_tflops, mfma_peak_tflops=FP64_PEAK_TFLOPS,
+                        mfma_frac=path_tflops / FP64_PEAK_TFLOPS,
+                        note=("achieved = SURVEY 8(d) bytes per trajectory-iteration x trajectory-iterations per pass / "
+                              "summed mean launch time of the pass's kernels (HIP events, every 4th step); path_* = the same "
+                              "bytes / flops over the wall time of a step (per GPU)"),
+                        event_sampled_steps=sampled, kernels=per)
         try:
             baseline_metric = json.load(open(os.path.join(ROOT, "BASELINE.json"))).get("metric")
         except Exception:
             baseline_metric = None
+        hist = {STATUS_NAMES.get(k, str(k)): int(v) for k, v in enumerate(hist_all) if v}
+        n_all = int(sum(hist_all))
         out = dict(metric="trajectories/sec", baseline_metric=baseline_metric, value=total_traj / dt,
                    unit="trajectories/sec", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step, higher_is_better=True,
@@ -225,24 +348,35 @@ def main():
                                if args.workload == "restarts" else
                                ("WAMReplannerExample receding horizon: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 SDF, "
                                 f"{B} warm-started windows per GPU, 3 fixed GN iterations"),
-                               restarts_per_gpu=B, total_step=N, obs_check_inter=p.setting.obs_check_inter,
+                               restarts_per_gpu=B, total_restarts=B * world, total_step=N,
+                               obs_check_inter=p.setting.obs_check_inter,
                                optimizer=args.opt, parallelism=f"trajectory-sharded x{world}"),
-                   gn_iters_to_tol=dict(min=int(iters.min()), median=float(np.median(iters)), max=int(iters.max())),
-                   traj_iters_per_sec=passes * world * args.steps / dt,
-                   status_counts={int(k): int(v) for k, v in zip(*np.unique(status, return_counts=True))},
+                   gn_iters_to_tol=dict(min=int(it_all.min()), median=float(np.median(it_all)), max=int(it_all.max())),
+                   traj_iters_per_sec=passes_all * args.steps / dt,
+                   status_counts=hist,
+                   rolled_back_share=float(hist.get("rolled_back", 0)) / max(n_all, 1),
+                   status_note=("rolled_back = the last iteration increased the error, so gpmp2::optimize returns the values "
+                                "before it (planner/BatchTrajOptimizer.cpp:297-307); iters-to-tol counts that last iteration"),
                    roofline=roof)
         if host_rate is not None:
             out["pcie_inclusive_value"] = host_rate
+        if variants:
+            out["variants"] = variants
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(os.cpu_count() or 1, 64))
             sample = args.cpu_sample or min(B, max(8, threads))
             sample = min(sample, 256)
             cb, ref = cpu_baseline(p, sample, threads)
-            # parity gate before the timing counts: same iteration counts as the oracle on the sample
-            cb["iters_match_gpu"] = bool(np.array_equal(ref["iters"], iters[:sample]))
+            # parity gate before the timing counts: every sampled restart against the oracle
+            res = plan.result()
+            cb.update(parity_vs_oracle(ref, (res["traj"], res["iters"], res["status"], res["final_error"]), sample))
+            s1 = max(1, min(sample, 8))
+            c1, _ = cpu_baseline(p, s1, 1)      # what the reference is: one thread
+            cb["single_thread"] = dict(value=c1["value"], unit=c1["unit"], cores=1, sample=c1["sample"], seconds=c1["seconds"])
             out["cpu_baseline"] = cb
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

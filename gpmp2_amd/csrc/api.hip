@@ -2,6 +2,7 @@
 // precomputation (GP matrices, whitening weights), marshalling and the optimizer driver loop.
 // There is deliberately no CPU compute path in this file: every entry point launches kernels.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -131,11 +132,18 @@ using namespace g2;
 struct gpmp2mi_robot {
   RobotDev h;
   RobotDev* d = nullptr;
+  ~gpmp2mi_robot() {
+    if (d) (void)hipFree(d);
+  }
 };
 struct gpmp2mi_sdf {
   SdfDev h;
   double* plain = nullptr;
   double* cells = nullptr;
+  ~gpmp2mi_sdf() {   // also runs when a create function fails half-way (unique_ptr)
+    if (plain) (void)hipFree(plain);
+    if (cells) (void)hipFree(cells);
+  }
 };
 
 struct KernelTimer {
@@ -317,11 +325,7 @@ int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
   *out = r.release();
   return GPMP2MI_OK;
 }
-void gpmp2mi_robot_destroy(gpmp2mi_robot* r) {
-  if (!r) return;
-  if (r->d) (void)hipFree(r->d);
-  delete r;
-}
+void gpmp2mi_robot_destroy(gpmp2mi_robot* r) { delete r; }
 int gpmp2mi_robot_dof(const gpmp2mi_robot* r) { return r ? r->h.dof : -1; }
 int gpmp2mi_robot_nr_links(const gpmp2mi_robot* r) { return r ? r->h.nr_links : -1; }
 int gpmp2mi_robot_nr_spheres(const gpmp2mi_robot* r) { return r ? r->h.nr_spheres : -1; }
@@ -465,16 +469,12 @@ int gpmp2mi_sdf_read_vol(const char* filename_pre, gpmp2mi_sdf** out) {
       }
   return gpmp2mi_sdf_create(3, origin, res, (int)cols, (int)rows, (int)nz, zyx.data(), GPMP2MI_SDF_LAYOUT_ZYX, out);
 }
-void gpmp2mi_sdf_destroy(gpmp2mi_sdf* s) {
-  if (!s) return;
-  if (s->plain) (void)hipFree(s->plain);
-  if (s->cells) (void)hipFree(s->cells);
-  delete s;
-}
+void gpmp2mi_sdf_destroy(gpmp2mi_sdf* s) { delete s; }
 
 int gpmp2mi_sdf_query(const gpmp2mi_sdf* s, int M, const double* pts, double* dist, double* grad, int* inr) {
   G2_CHECK(s && pts && dist && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
   if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
   DevBuf<double> dp, dd, dg;
   DevBuf<int> di;
   G2_TRY(dp.upload(pts, (size_t)M * s->h.dim));
@@ -521,6 +521,7 @@ void gpmp2mi_graph_opts_default(gpmp2mi_graph_opts* o) {
 int gpmp2mi_forward_kinematics(const gpmp2mi_robot* r, int M, const double* conf, double* poses, double* J) {
   G2_CHECK(r && conf && poses && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
   if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
   const int D = r->h.dof, L = r->h.nr_links;
   DevBuf<double> dq, dp, dj;
   G2_TRY(dq.upload(conf, (size_t)M * D));
@@ -536,6 +537,7 @@ int gpmp2mi_forward_kinematics(const gpmp2mi_robot* r, int M, const double* conf
 int gpmp2mi_sphere_centers(const gpmp2mi_robot* r, int M, const double* conf, double* centers, double* J) {
   G2_CHECK(r && conf && centers && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
   if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
   const int D = r->h.dof, S = r->h.nr_spheres;
   DevBuf<double> dq, dc, dj;
   G2_TRY(dq.upload(conf, (size_t)M * D));
@@ -611,6 +613,7 @@ int gpmp2mi_obstacle_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, double
                             const double* conf, double* err, double* H1) {
   G2_CHECK(r && s && conf && err && M >= 0, GPMP2MI_ERR_INVALID, "null argument");
   if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
   const int D = r->h.dof, S = r->h.nr_spheres;
   DevBuf<double> dq, de, dh;
   G2_TRY(dq.upload(conf, (size_t)M * D));
@@ -632,6 +635,7 @@ int gpmp2mi_obstacle_gp_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, dou
   const bool jac = H1 || H2 || H3 || H4;
   G2_CHECK(!jac || (H1 && H2 && H3 && H4), GPMP2MI_ERR_INVALID, "pass all four Jacobians or none");
   if (M == 0) return GPMP2MI_OK;
+  G2_TRY(ensure_device());
   const int D = r->h.dof, S = r->h.nr_spheres;
   DevBuf<double> a, b, c, d, de, h1, h2, h3, h4;
   G2_TRY(a.upload(c1, (size_t)M * D));
@@ -964,7 +968,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     p->generic_gn = e && e[0] == '1';
     const char* wd = getenv("GPMP2MI_WIDE_DENSE");
     p->wide_dense = wd && wd[0] == '1';
-    const int cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
+    const int cap = std::max(P.fixed_iters, P.max_iter);   // plan_update may run any iterations <= max_iter
     // passes: GN one per iteration (+1); LM up to ~5 lambda retries per iterate; Dogleg up to ~16 halvings
     const int mult = P.opt_type == GPMP2MI_OPT_LM ? 6 : P.opt_type == GPMP2MI_OPT_DOGLEG ? 18 : 1;
     p->n_active_len = cap * mult + 3;
@@ -1020,9 +1024,16 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
 
 // Active-trajectory count of a finished pass.  The closing kernel of every pass publishes it to a pinned,
 // device-mapped flag (publish_pass_count), so there is no copy command or event in the stream; the host spins
-// on the flag and falls back to the stream state if the flag never arrives (a faulted kernel).
-static int wait_pass_count(gpmp2mi_plan* p, int pass, hipStream_t st, int* count) {
-  volatile int* flag = p->h_flags + pass;
+// on the flag, falls back to the stream state if the flag never arrives (a faulted kernel) and gives up after a
+// wall-clock limit (GPMP2MI_WAIT_TIMEOUT_MS, default 5000) so that a hung kernel cannot hang the caller.
+static double wait_timeout_seconds() {
+  const char* e = getenv("GPMP2MI_WAIT_TIMEOUT_MS");
+  const double ms = e ? atof(e) : 5000.0;
+  return (ms > 0 ? ms : 5000.0) * 1e-3;
+}
+// `st_valid` false: no stream to query (the host-only test hook gpmp2mi_debug_wait_flag)
+static int spin_wait_flag(const volatile int* flag, bool st_valid, hipStream_t st, double timeout_s, int* count) {
+  const auto t0 = std::chrono::steady_clock::now();
   for (long spin = 0;; spin++) {
     const int v = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
     if (v >= 0) {
@@ -1030,20 +1041,31 @@ static int wait_pass_count(gpmp2mi_plan* p, int pass, hipStream_t st, int* count
       return GPMP2MI_OK;
     }
     if ((spin & 0xfff) == 0xfff) {
-      const hipError_t e = hipStreamQuery(st);
-      if (e == hipSuccess) {  // everything enqueued has run: the flag must be there now
-        const int w = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
-        G2_CHECK(w >= 0, GPMP2MI_ERR_HIP, "pass count was never published");
-        *count = w;
-        return GPMP2MI_OK;
+      if (st_valid) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) {  // everything enqueued has run: the flag must be there now
+          const int w = __atomic_load_n(flag, __ATOMIC_ACQUIRE);
+          G2_CHECK(w >= 0, GPMP2MI_ERR_HIP, "pass count was never published");
+          *count = w;
+          return GPMP2MI_OK;
+        }
+        if (e != hipErrorNotReady) G2_HIP(e);
       }
-      if (e != hipErrorNotReady) G2_HIP(e);
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el > timeout_s) {
+        set_error("timed out after " + std::to_string((int)(el * 1e3)) +
+                  " ms waiting for a pass to finish (kernel hung?); GPMP2MI_WAIT_TIMEOUT_MS raises the limit");
+        return GPMP2MI_ERR_HIP;
+      }
     }
   }
 }
+static int wait_pass_count(gpmp2mi_plan* p, int pass, hipStream_t st, int* count) {
+  return spin_wait_flag(p->h_flags + pass, true, st, wait_timeout_seconds(), count);
+}
 
 // the optimizer driver: `cur` holds the starting values
-static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
+static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
   const PlanParams& P = p->hp;
   PlanBuffers& pb = p->pb;
   p->timer.reset();
@@ -1122,11 +1144,20 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
         if (cnt == 0) break;
       }
     }
+    // pass budget spent with trajectories still iterating (many consecutive rejected trial steps): they
+    // finish with their current values and status MAX_ITER instead of returning a stale `result`
+    G2_TRY(launch_finalize_unfinished(P, pb, st));
   }
   G2_HIP(hipStreamSynchronize(st));
   if (p->timer.enabled) p->timer.collect();
   p->optimized = true;
   return GPMP2MI_OK;
+}
+static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
+  const int rc = plan_run_impl(p, st);
+  // error path: the next run resets the host flags assuming the stream has drained
+  if (rc != GPMP2MI_OK) (void)hipStreamSynchronize(st);
+  return rc;
 }
 
 static int plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status,
@@ -1261,6 +1292,7 @@ int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream) {
   G2_CHECK(p && iterations > 0, GPMP2MI_ERR_INVALID, "bad argument");
   G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
   G2_CHECK(iterations <= p->hp.max_iter, GPMP2MI_ERR_INVALID, "iterations exceeds max_iter");
+  G2_CHECK(iterations + 3 <= p->n_active_len, GPMP2MI_ERR_INVALID, "iterations exceeds the plan's pass budget");
   hipStream_t st = (hipStream_t)stream;
   // warm start: the previous estimate becomes the initial values of this run
   const double* from = p->optimized ? p->pb.result : p->pb.init;
@@ -1331,6 +1363,12 @@ int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(dout.download(out512));
   return GPMP2MI_OK;
+}
+
+// test hook (host only, no GPU needed): the bounded spin of the pass driver on a caller-owned flag
+int gpmp2mi_debug_wait_flag(const int* flag, int timeout_ms, int* value) {
+  G2_CHECK(flag && value && timeout_ms > 0, GPMP2MI_ERR_INVALID, "bad argument");
+  return spin_wait_flag(flag, false, nullptr, timeout_ms * 1e-3, value);
 }
 
 int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable) {

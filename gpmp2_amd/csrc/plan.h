@@ -108,6 +108,7 @@ int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* t
 int launch_solve_step(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_ghg(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool init, hipStream_t st);
+int launch_finalize_unfinished(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);

@@ -440,6 +440,26 @@ int launch_decide(const PlanParams& hp, const PlanBuffers& pb, int pass, bool in
   return GPMP2MI_OK;
 }
 
+// Trajectories that are still iterating when the trial-step driver has spent its pass budget: finish them with
+// their current values (status MAX_ITER) so that `result` is never stale.  One workgroup per trajectory.
+__global__ __launch_bounds__(256) void k_finalize_unfinished(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x;
+  if (!pb.active[b]) return;
+  const size_t tsz = (size_t)(P.N + 1) * P.n;
+  for (size_t k = threadIdx.x; k < tsz; k += blockDim.x) pb.result[b * tsz + k] = pb.cur[b * tsz + k];
+  if (threadIdx.x == 0) {
+    pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
+    pb.final_err[b] = pb.cur_err[b];
+    pb.active[b] = 0;
+  }
+}
+int launch_finalize_unfinished(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  k_finalize_unfinished<<<dim3(hp.B), dim3(256), 0, st>>>(pb.params, pb);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 // =============================================================================== export H, g
 template <int D, bool LIE>
 __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __restrict__ pp, PlanBuffers pb,

@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define GPMP2MI_VERSION 100
-#define GPMP2MI_MAX_DOF 10      /* largest dof any kernel is instantiated for */
+#define GPMP2MI_MAX_DOF 11      /* largest total dof a plan is instantiated for (csrc/common.h MAXD) */
 #define GPMP2MI_MAX_SPHERES 64  /* largest sphere model staged on chip */
 
 /* ---- status codes (replace the C++ exceptions of SURVEY.md section 8b "Error convention") --- */
@@ -395,6 +395,11 @@ int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable);
 int gpmp2mi_plan_get_timing(gpmp2mi_plan* p, int* n, const char** names, double* ms, int* launches);
 /* Diagnostic builds (-DG2_STAMPS) only: 64 raw s_memtime stamps of trajectory b's last solve step. */
 int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64);
+/* Test hook, host only (no GPU needed): the wall-clock-bounded spin the pass driver uses on its device-mapped
+ * pass flags, run on a caller-owned flag: returns GPMP2MI_OK with *value = *flag once *flag >= 0, or
+ * GPMP2MI_ERR_HIP (gpmp2mi_last_error set) after timeout_ms.  The driver's own limit is 5 s
+ * (GPMP2MI_WAIT_TIMEOUT_MS overrides). */
+int gpmp2mi_debug_wait_flag(const int* flag, int timeout_ms, int* value);
 /* Diagnostic: lane semantics of the wave-level moves the solver relies on (tests/test_gpu_plan.py). */
 int gpmp2mi_debug_crosslane(const double* in64, double* out512);
 

@@ -4,6 +4,8 @@ block-tridiagonal Cholesky, and the whole Gauss-Newton solve against the CPU ora
 Stated tolerances (BASELINE.md parity gate): normal-equation entries and gradients relative 1e-9
 of the block's largest entry; per-iteration graph error relative 1e-9; final trajectory absolute
 1e-6; identical per-trajectory iteration counts and status codes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -172,12 +174,25 @@ def test_plan_can_be_rerun_and_reused(engine, small_wam):
     assert not np.allclose(a["traj"], c["traj"])
 
 
-def test_full_size_headline_config_properties(engine, oracle):
-    """BASELINE config 3 at full size (WAM, N=100, I=5, 200^3 SDF): too slow to run the oracle on
-    all 64 restarts, so compare 2 restarts exactly and check size-independent properties on all."""
-    p = problems.wam_restarts(B=64)
+def _full_size_vs_oracle(engine, oracle, p):
+    """every restart of a full-size batch against the oracle (all host threads): iteration counts, status, final
+    error (1e-9 rel) and trajectory (1e-6 abs) -- SURVEY.md 8(d) parity gate"""
     r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
     res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init, nthreads=min(os.cpu_count() or 1, 64))
+    assert list(res["iters"]) == list(ref["iters"])
+    assert list(res["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+    return r, s, res
+
+
+def test_full_size_headline_config_properties(engine, oracle):
+    """BASELINE config 3 at full size (WAM, N=100, I=5, 200^3 SDF): ALL 64 restarts against the oracle, plus
+    size-independent properties."""
+    p = problems.wam_restarts(B=64)
+    r, s, res = _full_size_vs_oracle(engine, oracle, p)
     e0 = engine.graph_error(r, s, p.setting, *_args(p), p.init)
     ef = engine.graph_error(r, s, p.setting, *_args(p), res["traj"])
     assert np.all(ef < e0)
@@ -186,14 +201,6 @@ def test_full_size_headline_config_properties(engine, oracle):
     # start / end priors (sigma 1e-4) hold the end points
     np.testing.assert_allclose(res["traj"][:, 0, :7], p.start_conf, atol=1e-3)
     np.testing.assert_allclose(res["traj"][:, -1, :7], p.end_conf, atol=1e-3)
-    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
-    sel = [0, 17]
-    ref = oracle.batch_optimize(ro, so, p.setting, p.start_conf[sel], p.start_vel[sel], p.end_conf[sel],
-                                p.end_vel[sel], p.init[sel], nthreads=2)
-    assert list(res["iters"][sel]) == list(ref["iters"])
-    assert list(res["status"][sel]) == list(ref["status"])
-    np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
-    np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
 
 
 def test_crosslane_primitives(engine):
@@ -252,17 +259,39 @@ def test_generic_path_reproduces_fused_gauss_newton(engine, small_wam, monkeypat
     np.testing.assert_allclose(a["final_error"], b["final_error"], rtol=1e-10)
 
 
-def test_full_size_headline_config_lm(engine, oracle):
-    p = problems.wam_restarts(B=8, opt="LM")
-    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
-    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
-    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
-    sel = [0, 5]
-    ref = oracle.batch_optimize(ro, so, p.setting, p.start_conf[sel], p.start_vel[sel], p.end_conf[sel],
-                                p.end_vel[sel], p.init[sel], nthreads=2)
-    assert list(res["iters"][sel]) == list(ref["iters"])
-    np.testing.assert_allclose(res["final_error"][sel], ref["final_error"], rtol=1e-9)
-    np.testing.assert_allclose(res["traj"][sel], ref["traj"], atol=1e-6)
+@pytest.mark.parametrize("opt,B", [("LM", 16), ("DOGLEG", 16)])
+def test_full_size_headline_config_lm_dogleg(engine, oracle, opt, B):
+    """the optimizers the reference's WAM scripts use (matlab/WAMFactorGraphExample.m:158-166 LM,
+    WAMPlannerExample.m:118 Dogleg) at the headline size, every restart against the oracle"""
+    _full_size_vs_oracle(engine, oracle, problems.wam_restarts(B=B, opt=opt))
+
+
+def update_beyond_budget_check(engine, oracle, p):
+    """gpmp2mi_plan_update(iterations) with iterations > the plan's fixed_iterations (any value <= max_iter is
+    legal): the pass arrays are sized for it, and the result is the oracle's warm-started run."""
+    import copy
+    p.setting.setGaussNewton()
+    p.setting.fixed_iterations = 1
+    r, s, ro, so = _handles(engine, oracle, p)
+    pl = engine.plan(r, s, p.setting, p.B)
+    pl.set_problem(*_args(p), p.init)
+    pl.optimize()
+    first = pl.result()
+    assert list(first["iters"]) == [1] * p.B
+    pl.update(iterations=5)
+    got = pl.result()
+    st = copy.copy(p.setting)
+    st.fixed_iterations = 5
+    ref = oracle.batch_optimize(ro, so, st, *_args(p), first["traj"])
+    assert list(got["iters"]) == [5] * p.B
+    np.testing.assert_allclose(got["traj"], ref["traj"], atol=1e-6)
+    np.testing.assert_allclose(got["final_error"], ref["final_error"], rtol=1e-8)
+    with pytest.raises(Exception):
+        pl.update(iterations=p.setting.max_iter + 1)
+
+
+def test_update_beyond_the_fixed_iteration_budget(engine, oracle):
+    update_beyond_budget_check(engine, oracle, problems.wam_restarts(B=3, total_step=10, obs_check_inter=2, sdf="40"))
 
 
 # ------------------------------------------------------------------ Pose2 (Lie) path, BASELINE config 5

@@ -265,3 +265,9 @@ def test_wide_robot_replanning(engine, oracle):
     ref = oracle.batch_optimize_xp(ro, so, st, p.start_conf, p.start_vel, goal2[None], p.end_vel, first, priors, [1])
     np.testing.assert_allclose(got["traj"], ref["traj"], atol=1e-6)
     np.testing.assert_allclose(got["traj"][0, 4], first[0, 4], atol=1e-3)
+
+
+def test_wide_robot_update_beyond_the_fixed_iteration_budget(engine, oracle):
+    """plan created with fixed_iterations = 1, update(iterations = 5) on the 2x2-tile path (trial-step driver)"""
+    from test_gpu_plan import update_beyond_budget_check
+    update_beyond_budget_check(engine, oracle, _tree_problem(_wide_models()["mobile WAM (dof 10)"], N=10, inter=2, opt="GN"))

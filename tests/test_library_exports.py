@@ -39,6 +39,30 @@ def test_no_silent_fallback_without_gpu():
         eng.joint_limit_factor([-1.0], [1.0], [0.1], np.zeros((1, 1)))
 
 
+def test_pass_driver_spin_is_bounded():
+    """the host spin on the device-mapped pass flags gives up after a wall-clock limit (a hung kernel must not
+    hang the caller): pointed at a flag that never flips it returns ERR_HIP with a message; a set flag is read"""
+    import time
+    lib = ctypes.CDLL(LIB)
+    lib.gpmp2mi_last_error.restype = ctypes.c_char_p
+    flag, val = ctypes.c_int(-1), ctypes.c_int(-7)
+    t0 = time.perf_counter()
+    rc = lib.gpmp2mi_debug_wait_flag(ctypes.byref(flag), 60, ctypes.byref(val))
+    el = time.perf_counter() - t0
+    assert rc == 3 and b"timed out" in lib.gpmp2mi_last_error()
+    assert 0.05 <= el < 2.0
+    flag.value = 5
+    assert lib.gpmp2mi_debug_wait_flag(ctypes.byref(flag), 60, ctypes.byref(val)) == 0 and val.value == 5
+
+
+def test_public_max_dof_matches_the_library():
+    hdr = open(os.path.join(ROOT, "include", "gpmp2mi.h")).read()
+    com = open(os.path.join(ROOT, "gpmp2_amd", "csrc", "common.h")).read()
+    pub = int(re.search(r"#define GPMP2MI_MAX_DOF (\d+)", hdr).group(1))
+    lib = int(re.search(r"constexpr int MAXD = (\d+);", com).group(1))
+    assert pub == lib
+
+
 def test_product_package_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "gpmp2_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -62,3 +62,18 @@ def test_two_rank_gloo_gather_matches_single_process(tmp_path, oracle):
     ref = oracle.batch_optimize(r, s, p.setting, p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
     np.testing.assert_array_equal(got["iters"], ref["iters"])
     np.testing.assert_array_equal(got["traj"], ref["traj"])
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts 2 ranks itself (child torchrun, parent never touches
+    the GPU).  Without GPUs the ranks refuse loudly instead of reporting a 1-GPU number as n_gpus 2."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a box with fewer than 2 GPUs to observe the refusal")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GPMP2MI_BENCH_REHEARSAL")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode != 0
+    assert out.stdout.strip() == ""                       # no JSON line from a run that did not happen
+    assert out.stderr.count("2 ranks requested but only") >= 1
