@@ -815,10 +815,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 11");
   const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: dense block path
   {
-    // the assembler stages an interval with at most NLD loads per lane (assembler.h: 10, 16 on the wide path)
+    // the assembler stages an interval with at most NLD2 16-B loads per lane (assembler.h: 6, 9 on the wide path)
     const int nd = D * (D + 1) / 2 + D + 1 + ((robot->h.base_dof == 3 && s->obs_check_inter > 0) ? 36 : 0);
     const int gpr = 2 * D + 1 + (robot->h.base_dof == 3 ? 18 : 0);
-    G2_CHECK((s->obs_check_inter + 1) * nd + gpr <= 64 * (wide ? 16 : 10), GPMP2MI_ERR_UNSUPPORTED,
+    const int nds = (nd + 1) & ~1, gps = (gpr + 1) & ~1;
+    G2_CHECK((s->obs_check_inter + 1) * nds + gps + 24 * s->obs_check_inter <= 2 * 64 * (wide ? 9 : 6), GPMP2MI_ERR_UNSUPPORTED,
              "obs_check_inter too large for the staged assembly");
   }
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
@@ -849,6 +850,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.wide = wide ? 1 : 0;
   P.split_back = (P.N >= 8 && !wide) ? 1 : 0;
   P.GPREC = P.n + 1 + (P.lie ? 18 : 0);
+  P.RECS = (P.REC + 1) & ~1;
+  P.GPS = (P.GPREC + 1) & ~1;
   P.obs_skip_first = o.obs_skip_first_state;
   P.flag_pos_limit = s->flag_pos_limit;
   P.flag_vel_limit = s->flag_vel_limit;
@@ -873,7 +876,19 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.lm_lower = o.lm_lambda_lower;
   P.lm_min_fidelity = o.lm_min_model_fidelity;
   P.dl_delta0 = o.dogleg_delta_initial;
-  for (int j = 0; j < P.I; j++) P.coef[j] = gp_coef(P.delta_t, inter_dt * static_cast<double>(j + 1));
+  for (int j = 0; j < P.I; j++) {
+    P.coef[j] = gp_coef(P.delta_t, inter_dt * static_cast<double>(j + 1));
+    const double lam[2] = {P.coef[j].l11, P.coef[j].l12}, psi[2] = {P.coef[j].p11, P.coef[j].p12};
+    double* q = P.coefq[j];
+    for (int ar = 0; ar < 2; ar++)
+      for (int ac = 0; ac < 2; ac++) {
+        q[0 + ar * 2 + ac] = psi[ar] * psi[ac];
+        q[4 + ar * 2 + ac] = lam[ar] * lam[ac];
+        q[8 + ar * 2 + ac] = lam[ar] * psi[ac];
+        q[12 + ar * 2 + ac] = psi[ar] * lam[ac];
+      }
+    q[16] = lam[0]; q[17] = lam[1]; q[18] = psi[0]; q[19] = psi[1];
+  }
   gp_winv(P.delta_t, P.Winv);
   std::vector<double> Qc(D * D, 0.0), Qi(D * D, 0.0);
   for (int i = 0; i < D; i++) Qc[i * D + i] = 1.0;
@@ -945,10 +960,10 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     G2_HIP(hipMemcpy(pb.goal_on, ones.data(), B * sizeof(int), hipMemcpyHostToDevice));
     p->h_xp_n.assign(B, 0);
   }
-  G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.REC * P.Ppad));
-  G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.REC * P.Ppad));
-  G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * P.GPREC * P.Npad));
-  G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * P.GPREC * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.rec, (size_t)B * P.RECS * P.Ppad));
+  G2_TRY(plan_alloc(p.get(), &pb.rec2, (size_t)B * P.RECS * P.Ppad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu, (size_t)B * P.GPS * P.Npad));
+  G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * P.GPS * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256 * tq));
   G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768 * tq));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));

@@ -19,23 +19,27 @@ template <int D, bool LIE>
 struct Assembler {
   static constexpr int n = 2 * D, NG = D * (D + 1) / 2, RECP = NG + D + 1;  // per-point record
   static constexpr int GPN = n + 1 + GP_EXTRA_LIE;
+  static constexpr int CQ = 24;            // doubles per sub-step in the staged weight table (PlanParams::coefq)
   static constexpr int PT_EXTRA_LIE = 36;  // M1..M4 (3x3 pose blocks of the interpolation Jacobians)
   static constexpr int RECMAX = RECP + PT_EXTRA_LIE;
 
   // LDS image of one interval (dynamic shared memory, sized at launch from I and the record
-  // lengths): pts[jj][REC] for jj = 0..I (I = unary of the end state), then the GP record
-  // u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)]
+  // lengths): pts[jj][RECS] for jj = 0..I (I = unary of the end state), then the GP record
+  // u = Q^-1 r (n), r^T u, [J1 (9), J3 (9)] padded to GPS, then the weight table of the I sub-steps (CQ doubles
+  // each, PlanParams::coefq: the four 2x2 products of the interpolation scalars + the scalars themselves)
   struct Slot {
     double* base;
-    int rec;   // P.REC
+    int rec;   // P.RECS (record stride, even)
     int npts;  // I + 1
+    int gps;   // P.GPS
     __device__ __forceinline__ double* pt(int jj) const { return base + jj * rec; }
     __device__ __forceinline__ const double* gpr() const { return base + npts * rec; }
     __device__ __forceinline__ double* gpw() const { return base + npts * rec; }
+    __device__ __forceinline__ const double* coef(int jj) const { return base + npts * rec + gps + CQ * jj; }
   };
-  __host__ __device__ static int slot_doubles(int I, int REC, int GPREC) { return (I + 1) * REC + GPREC; }
+  __host__ __device__ static int slot_doubles(int I, int RECS, int GPS) { return (I + 1) * RECS + GPS + CQ * I; }
   __device__ __forceinline__ Slot make_slot(double* smem, int which) const {
-    return Slot{smem + which * slot_doubles(P.I, P.REC, P.GPREC), P.REC, P.I + 1};
+    return Slot{smem + which * slot_doubles(P.I, P.RECS, P.GPS), P.RECS, P.I + 1, P.GPS};
   }
 
   const PlanParams& P;
@@ -44,6 +48,7 @@ struct Assembler {
   const double* gpu;
   int b, lane, c, g;   // c / g: this lane's global column / first global row (tile offsets included)
   int rhscol;          // column that carries the right-hand side (-g_i)
+  int row0, col0;      // offset of this 16x16 tile inside a wider block
   // per-lane static decode of its 4 rows
   int tri[4];
   bool valid[4];   // rho < n && c < n
@@ -52,9 +57,9 @@ struct Assembler {
   // row0 / col0: offset of the 16x16 tile inside a wider block (blocks with 2 dof > 15 are exported as
   // 2x2 tiles by k_export_normal_eq); rhscol_: global column of the right-hand side
   __device__ Assembler(const PlanParams& P_, const PlanBuffers& pb_, const double* rec_, const double* gpu_,
-                       int b_, int lane_, int row0 = 0, int col0 = 0, int rhscol_ = RHSCOL)
-      : P(P_), pb(pb_), rec(rec_), gpu(gpu_), b(b_), lane(lane_), c(col0 + (lane_ & 15)), g(row0 + (lane_ >> 4)),
-        rhscol(rhscol_) {
+                       int b_, int lane_, int row0_ = 0, int col0_ = 0, int rhscol_ = RHSCOL)
+      : P(P_), pb(pb_), rec(rec_), gpu(gpu_), b(b_), lane(lane_), c(col0_ + (lane_ & 15)), g(row0_ + (lane_ >> 4)),
+        rhscol(rhscol_), row0(row0_), col0(col0_) {
     a_col = c >= D;
     k_col = c - a_col * D;
 #pragma unroll
@@ -69,36 +74,38 @@ struct Assembler {
   }
 
   // global -> registers -> LDS for the two intervals a block needs (iv and iv + 1; interval 0 is
-  // only the unary point of state 0, intervals beyond N read as zeros).  All loads of both intervals
-  // are issued before the first LDS store so the wavefront pays one memory latency, not one per
-  // 64 values; NLD bounds the per-lane load count (checked on the host).
-  static constexpr int NLD = (D <= 7) ? 10 : 16;
+  // only the unary point of state 0, intervals beyond N read as zeros).  The records are point-major
+  // (rec[b][p][RECS], gpu[b][i][GPS]), so an interval is ONE contiguous run of (I + 1) * RECS doubles: every
+  // lane moves 16-B pieces, fully coalesced.  All loads of both intervals are issued before the first
+  // LDS store so the wavefront pays one memory latency; NLD2 bounds the per-lane load count (checked on
+  // the host).  The weight table of the sub-steps rides along into the slot (LDS reads later instead of scalar
+  // loads and per-entry products inside the accumulation loops).
+  static constexpr int NLD2 = (D <= 7) ? 6 : 9;
   // count = 1 stages interval iv only (kernels whose wavefronts share their slots)
   __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1, int count = 2) const {
-    const int I = P.I;
-    const double* rb = rec + (size_t)b * P.REC * P.Ppad;
-    const double* gb = gpu + (size_t)b * P.GPREC * P.Npad;
-    double val[2][NLD];
+    const int I = P.I, RECS = P.RECS, GPS = P.GPS;
+    double2 val[2][NLD2];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
       if (w >= count) break;
       const int ivw = iv + w;
       const int npt = (ivw == 0) ? 1 : I + 1;
-      const int nv = P.REC * npt;
+      const int nd2 = (npt * RECS) >> 1, ng2 = GPS >> 1, nc2 = (CQ / 2) * I;
       const int p0 = (ivw == 0) ? 0 : 1 + (ivw - 1) * (I + 1);
       const bool in_range = ivw <= P.N;
-      const float inv_npt = 1.0f / (float)npt;
+      const double2* src = reinterpret_cast<const double2*>(rec + ((size_t)b * P.Ppad + p0) * RECS);
+      const double2* gsrc = reinterpret_cast<const double2*>(gpu + ((size_t)b * P.Npad + ivw) * GPS);
+      const double2* csrc = reinterpret_cast<const double2*>(P.coefq);
 #pragma unroll
-      for (int m = 0; m < NLD; m++) {
+      for (int m = 0; m < NLD2; m++) {
         const int v = lane + 64 * m;
-        double x = 0.0;
-        if (in_range && v < nv + P.GPREC) {
-          if (v < nv) {
-            const int k = (int)(((float)v + 0.5f) * inv_npt), jj = v - k * npt;  // exact for v < 2^20
-            x = rb[(size_t)k * P.Ppad + p0 + jj];
-          } else if (ivw > 0) {
-            x = gb[(size_t)(v - nv) * P.Npad + ivw];
-          }
+        double2 x = {0.0, 0.0};
+        if (v < nd2) {
+          if (in_range) x = src[v];
+        } else if (v < nd2 + ng2) {
+          if (in_range && ivw > 0) x = gsrc[v - nd2];
+        } else if (v < nd2 + ng2 + nc2) {
+          x = csrc[v - nd2 - ng2];
         }
         val[w][m] = x;
       }
@@ -109,17 +116,14 @@ struct Assembler {
       const Slot& s = w ? s1 : s0;
       const int ivw = iv + w;
       const int npt = (ivw == 0) ? 1 : I + 1;
-      const int nv = P.REC * npt;
-      const float inv_npt = 1.0f / (float)npt;
+      const int nd2 = (npt * RECS) >> 1, ng2 = GPS >> 1, nc2 = (CQ / 2) * I;
+      double2* dpt = reinterpret_cast<double2*>(s.pt((ivw == 0) ? I : 0));
+      double2* dgp = reinterpret_cast<double2*>(s.gpw());
 #pragma unroll
-      for (int m = 0; m < NLD; m++) {
+      for (int m = 0; m < NLD2; m++) {
         const int v = lane + 64 * m;
-        if (v < nv) {
-          const int k = (int)(((float)v + 0.5f) * inv_npt), jj = v - k * npt;
-          s.pt((ivw == 0) ? I : jj)[k] = val[w][m];
-        } else if (v < nv + P.GPREC) {
-          s.gpw()[v - nv] = val[w][m];
-        }
+        if (v < nd2) dpt[v] = val[w][m];
+        else if (v < nd2 + ng2 + nc2) dgp[v - nd2] = val[w][m];
       }
     }
   }
@@ -169,6 +173,12 @@ struct Assembler {
   // lane's share of the block's graph-error contribution (to be wave-summed; not yet halved).
   // si = slot of interval i (its unary point is state i), sn = slot of interval i+1; z = state i.
   // want_c: also build the couplings (only odd blocks and the export / Dogleg paths need them).
+  //
+  // Two phases.  (1) Row-owner lanes: lane r < 16 owns row row0 + r of the tile and forms that row's diagonal
+  // additions (priors, limits, dynamics, replanner priors), its gradient entry and its error share -- every
+  // global load this needs is issued once, at the top, by all owner lanes together.  (2) All lanes form the matrix
+  // entries from the LDS records; the owners' values are then dropped into the diagonal and the rhs column with
+  // wave shuffles.
   __device__ __forceinline__ double build_tiles(int i, const Slot& si, const Slot& sn, const double* z, Tile& S,
                                                 Tile& Cl, Tile& Cr, bool want_c) const {
     const int I = P.I, N = P.N;
@@ -179,118 +189,28 @@ struct Assembler {
     const double* J1n = sn.gpr() + n + 1;       // of interval i+1 (state i is the first state)
     const double* J1i = si.gpr() + n + 1;
     const double* J3n = sn.gpr() + n + 1 + 9;
-    double dk[4] = {0, 0, 0, 0}, hrk[4] = {0, 0, 0, 0}, hlk[4] = {0, 0, 0, 0};
-    const int ac = a_col, kc = k_col;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (!valid[k]) continue;
-      const int ar = a_row[k], kr = k_row[k], rho = g + 4 * k;
-      double d = 0.0, hr = 0.0, hl = 0.0;
-      if (!lie) {
-        // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
-        // KO = -Phi^T Q^-1 = H_{i,i+1}
-        d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
-        if (want_c) {
-          hr = has_next ? P.KO[rho * n + c] : 0.0;
-          hl = has_prev ? P.KO[c * n + rho] : 0.0;
-        }
-      } else {
-        // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
-        const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
-        if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
-          const double* L = ar ? nullptr : J3i;
-          d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
-          if (want_c) hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
-        }
-        if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
-          const double* L = ar ? nullptr : J1n;
-          d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
-          if (want_c) hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
-        }
-      }
-      if (!ar && !ac) d += si.pt(I)[tri[k]];  // unary obstacle factor at state i
-      dk[k] = d;
-      hrk[k] = hr;
-      hlk[k] = hl;
-    }
-    // interpolated obstacle factors: interval i (state i second) and interval i+1 (state i first)
-    for (int jj = 0; jj < I; jj++) {
-      const GpCoef cf = P.coef[jj];
-      const double w1c = ac ? cf.l12 : cf.l11, w2c = ac ? cf.p12 : cf.p11;
-      const double* pp_ = si.pt(jj);
-      const double* pn_ = sn.pt(jj);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (!valid[k]) continue;
-        const int ar = a_row[k], kr = k_row[k];
-        const double w1r = ar ? cf.l12 : cf.l11, w2r = ar ? cf.p12 : cf.p11;
-        if (lie) {
-          // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
-          if (has_prev) {
-            const double* M = pp_ + RECP;
-            dk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
-            if (want_c) hlk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
-          }
-          if (has_next) {
-            const double* M = pn_ + RECP;
-            dk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
-            if (want_c) hrk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
-          }
-          continue;
-        }
-        const int t = tri[k];
-        if (has_prev) {
-          const double Gp = pp_[t];
-          dk[k] = fma(w2r * w2c, Gp, dk[k]);
-          if (want_c) hlk[k] = fma(w2r * w1c, Gp, hlk[k]);  // rows: state i (second), cols: state i-1 (first)
-        }
-        if (has_next) {
-          const double Gn = pn_[t];
-          dk[k] = fma(w1r * w1c, Gn, dk[k]);
-          if (want_c) hrk[k] = fma(w1r * w2c, Gn, hrk[k]);  // rows: state i (first), cols: state i+1 (second)
-        }
-      }
-    }
+
+    // ---------------------------------------------------------------- phase 1: row owners
+    const bool need_diag = (row0 == col0), need_rhs = (rhscol >= col0 && rhscol < col0 + 16);
+    const int orow = row0 + lane;                       // the row this lane owns (lanes 0..15)
+    const bool owner = lane < 16 && orow < n && (need_diag || need_rhs);
     const int nxp = pb.xp_n[b];
-    for (int e = 0; e < nxp; e++) {
-      const size_t xe = (size_t)b * XP_MAX + e;
-      if (pb.xp_state[xe] != i) continue;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        // the diagonal entries are added with the other diagonal terms below
-        if (!valid[k] || a_row[k] != ac || (ac && !pb.xp_has_vel[xe]) || (g + 4 * k) == c) continue;
-        dk[k] += pb.xp_info[(xe * 2 + ac) * D * D + (size_t)k_row[k] * D + kc];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      S.r[k] = dk[k];
-      Cr.r[k] = hrk[k];
-      Cl.r[k] = hlk[k];
-    }
-    // this block's share of the graph error: unary point of state i, the interpolated points and the
-    // GP prior of the interval ending at i, plus (below) the prior / limit / dynamics terms of state i
-    double err_acc = 0.0;
-    if (lane <= I && (lane == I || has_prev)) err_acc = si.pt(lane)[NG + D];
-    if (lane == 63 && has_prev) err_acc += si.gpr()[n];
-    // diagonal terms (priors, limits, dynamics) and the gradient column (-g_i in column RHSCOL)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int rho = g + 4 * k;
-      if (rho >= n) continue;
-      const bool on_diag = (c == rho), on_rhs = (c == rhscol);
-      if (!on_diag && !on_rhs) continue;
-      const int ar = a_row[k], kr = k_row[k];
-      double dd = 0.0, gg = 0.0, ee = 0.0;
+    double o_dd = 0.0, o_gg = 0.0, o_ee = 0.0;
+    if (owner) {
+      const int rho = orow, ar = rho >= D, kr = rho - ar * D;
+      const bool prior_here = (i == 0 || (i == N && pb.goal_on[b]));
       const double zz = z[rho];
-      if (i == 0 || (i == N && pb.goal_on[b])) {  // PriorFactor on x_0, v_0, x_N, v_N  (BatchTrajOptimizer-inl.h:41-48)
+      double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+      if (lie) { z0 = z[0]; z1 = z[1]; z2 = z[2]; }
+      double dd = 0.0, gg = 0.0, ee = 0.0;
+      if (prior_here) {  // PriorFactor on x_0, v_0, x_N, v_N  (BatchTrajOptimizer-inl.h:41-48)
         const double* tg = (i == 0) ? (ar ? pb.start_vel : pb.start_conf) : (ar ? pb.end_vel : pb.end_conf);
         tg += (size_t)b * D;
         const double w = ar ? P.vel_prior_w : P.conf_prior_w;
         double dz = zz - tg[kr];
         if (lie && !ar && kr < 3) {
           // gtsam 4.0 PriorFactor<Pose2Vector>: error = -Local(x, prior), H = I
-          const P2 bt = pose2_between(P2{z[0], z[1], z[2]}, P2{tg[0], tg[1], tg[2]});
+          const P2 bt = pose2_between(P2{z0, z1, z2}, P2{tg[0], tg[1], tg[2]});
           dz = -(kr == 0 ? bt.x : kr == 1 ? bt.y : bt.th);
         }
         dd += w;
@@ -326,7 +246,7 @@ struct Assembler {
         for (int cc = 0; cc < D; cc++) {
           double rc = z[ar * D + cc] - tg[cc];
           if (lie && !ar && cc < 3) {
-            const P2 bt = pose2_between(P2{z[0], z[1], z[2]}, P2{tg[0], tg[1], tg[2]});
+            const P2 bt = pose2_between(P2{z0, z1, z2}, P2{tg[0], tg[1], tg[2]});
             rc = -(cc == 0 ? bt.x : cc == 1 ? bt.y : bt.th);
           }
           wr = fma(Wm[cc], rc, wr);
@@ -336,21 +256,18 @@ struct Assembler {
         gg += wr;
         ee += wr * rk;
       }
-      if (on_diag) {
-        S.r[k] += dd;
-        err_acc += ee;
-      }
-      if (on_rhs) {
+      if (need_rhs) {
         if (!ar) gg += si.pt(I)[NG + kr];
         for (int jj = 0; jj < I; jj++) {
-          const GpCoef cf = P.coef[jj];
+          const double* cf = si.coef(jj) + 16;     // l11 l12 p11 p12
+          const double cp = ar ? cf[3] : cf[2], cl = ar ? cf[1] : cf[0];
           if (lie) {
-            if (has_prev) gg += hint_vec(si.pt(jj), si.pt(jj) + RECP + (ar ? 27 : 18), ar ? cf.p12 : cf.p11, kr);
-            if (has_next) gg += hint_vec(sn.pt(jj), sn.pt(jj) + RECP + (ar ? 9 : 0), ar ? cf.l12 : cf.l11, kr);
+            if (has_prev) gg += hint_vec(si.pt(jj), si.pt(jj) + RECP + (ar ? 27 : 18), cp, kr);
+            if (has_next) gg += hint_vec(sn.pt(jj), sn.pt(jj) + RECP + (ar ? 9 : 0), cl, kr);
             continue;
           }
-          if (has_prev) gg = fma(ar ? cf.p12 : cf.p11, si.pt(jj)[NG + kr], gg);
-          if (has_next) gg = fma(ar ? cf.l12 : cf.l11, sn.pt(jj)[NG + kr], gg);
+          if (has_prev) gg = fma(cp, si.pt(jj)[NG + kr], gg);
+          if (has_next) gg = fma(cl, sn.pt(jj)[NG + kr], gg);
         }
         if (!lie) {
           // GP prior gradient: + Phi^T u_{i+1} - u_i
@@ -369,8 +286,181 @@ struct Assembler {
             else gg += si.gpr()[kr];
           }
         }
-        S.r[k] = -gg;
       }
+      o_dd = dd;
+      o_gg = gg;
+      o_ee = need_diag ? ee : 0.0;
+    }
+
+    // ---------------------------------------------------------------- phase 2: matrix entries
+    double dk[4] = {0, 0, 0, 0}, hrk[4] = {0, 0, 0, 0}, hlk[4] = {0, 0, 0, 0};
+    const int ac = a_col, kc = k_col;
+    if constexpr (!lie) {
+      // Vector-space robots: branch-free per entry.  Lanes / rows outside the n x n block compute on clamped
+      // indices and are zeroed at the end, so there is no per-entry exec masking.  Entry (rho, c) of
+      //   D_i      = KB + KA + [xx] G_unary + sum_jj Psi_r Psi_c G_jj(interval i) + Lam_r Lam_c G_jj(interval i+1)
+      //   H_{i,i+1} = KO   + sum_jj Lam_r Psi_c G_jj(interval i+1),   H_{i,i-1} = KO^T + sum_jj Psi_r Lam_c G_jj(interval i)
+      // with the 2x2 weight products read from the staged table (coefq) at [quad * 4 + ar * 2 + ac].
+      const int cc_ = min(c, n - 1);
+      const double fp = has_prev ? 1.0 : 0.0, fn = has_next ? 1.0 : 0.0;
+      int wq[4];
+      const double* un = si.pt(I);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int rr_ = min(g + 4 * k, n - 1);
+        wq[k] = a_row[k] * 2 + ac;
+        double d = fp * P.KB[rr_ * n + cc_] + fn * P.KA[rr_ * n + cc_];
+        const double u = un[tri[k]];
+        d += (wq[k] == 0) ? u : 0.0;            // unary obstacle factor at state i: the xx quadrant
+        dk[k] = d;
+        if (want_c) {
+          hrk[k] = fn * P.KO[rr_ * n + cc_];
+          hlk[k] = fp * P.KO[cc_ * n + rr_];
+        }
+      }
+      if (has_prev && has_next) {
+#pragma unroll 1
+        for (int jj = 0; jj < I; jj++) {
+          const double* cq = si.coef(jj);
+          const double* pp_ = si.pt(jj);
+          const double* pn_ = sn.pt(jj);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double Gp = pp_[tri[k]], Gn = pn_[tri[k]];
+            dk[k] = fma(cq[wq[k]], Gp, dk[k]);
+            dk[k] = fma(cq[4 + wq[k]], Gn, dk[k]);
+            if (want_c) {
+              hrk[k] = fma(cq[8 + wq[k]], Gn, hrk[k]);
+              hlk[k] = fma(cq[12 + wq[k]], Gp, hlk[k]);
+            }
+          }
+        }
+      } else {
+        for (int jj = 0; jj < I; jj++) {
+          const double* cq = si.coef(jj);
+          const double* pp_ = si.pt(jj);
+          const double* pn_ = sn.pt(jj);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            if (has_prev) {
+              const double Gp = pp_[tri[k]];
+              dk[k] = fma(cq[wq[k]], Gp, dk[k]);
+              if (want_c) hlk[k] = fma(cq[12 + wq[k]], Gp, hlk[k]);
+            }
+            if (has_next) {
+              const double Gn = pn_[tri[k]];
+              dk[k] = fma(cq[4 + wq[k]], Gn, dk[k]);
+              if (want_c) hrk[k] = fma(cq[8 + wq[k]], Gn, hrk[k]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        dk[k] = valid[k] ? dk[k] : 0.0;
+        hrk[k] = valid[k] ? hrk[k] : 0.0;
+        hlk[k] = valid[k] ? hlk[k] : 0.0;
+      }
+    } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (!valid[k]) continue;
+      const int ar = a_row[k], kr = k_row[k], rho = g + 4 * k;
+      double d = 0.0, hr = 0.0, hl = 0.0;
+      if (!lie) {
+        // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
+        // KO = -Phi^T Q^-1 = H_{i,i+1}
+        d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
+        if (want_c) {
+          hr = has_next ? P.KO[rho * n + c] : 0.0;
+          hl = has_prev ? P.KO[c * n + rho] : 0.0;
+        }
+      } else {
+        // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
+        const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
+        if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
+          const double* L = ar ? nullptr : J3i;
+          d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
+          if (want_c) hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
+        }
+        if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
+          const double* L = ar ? nullptr : J1n;
+          d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
+          if (want_c) hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
+        }
+      }
+      if (!ar && !ac) d += si.pt(I)[tri[k]];  // unary obstacle factor at state i
+      dk[k] = d;
+      hrk[k] = hr;
+      hlk[k] = hl;
+    }
+    // interpolated obstacle factors: interval i (state i second) and interval i+1 (state i first)
+#pragma unroll 1
+    for (int jj = 0; jj < I; jj++) {
+      const double* cf = si.coef(jj) + 16;       // l11 l12 p11 p12 (broadcast LDS reads)
+      const double w1c = ac ? cf[1] : cf[0], w2c = ac ? cf[3] : cf[2];
+      const double w1x = cf[0], w1v = cf[1], w2x = cf[2], w2v = cf[3];
+      const double* pp_ = si.pt(jj);
+      const double* pn_ = sn.pt(jj);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (!valid[k]) continue;
+        const int ar = a_row[k], kr = k_row[k];
+        const double w1r = ar ? w1v : w1x, w2r = ar ? w2v : w2x;
+        if (lie) {
+          // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
+          if (has_prev) {
+            const double* M = pp_ + RECP;
+            dk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
+            if (want_c) hlk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
+          }
+          if (has_next) {
+            const double* M = pn_ + RECP;
+            dk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
+            if (want_c) hrk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
+          }
+          continue;
+        }
+        const int t = tri[k];
+        if (has_prev) {
+          const double Gp = pp_[t];
+          dk[k] = fma(w2r * w2c, Gp, dk[k]);
+          if (want_c) hlk[k] = fma(w2r * w1c, Gp, hlk[k]);  // rows: state i (second), cols: state i-1 (first)
+        }
+        if (has_next) {
+          const double Gn = pn_[t];
+          dk[k] = fma(w1r * w1c, Gn, dk[k]);
+          if (want_c) hrk[k] = fma(w1r * w2c, Gn, hrk[k]);  // rows: state i (first), cols: state i+1 (second)
+        }
+      }
+    }
+    }
+    for (int e = 0; e < nxp; e++) {
+      const size_t xe = (size_t)b * XP_MAX + e;
+      if (pb.xp_state[xe] != i) continue;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // the diagonal entries arrive with the owners' values below
+        if (!valid[k] || a_row[k] != ac || (ac && !pb.xp_has_vel[xe]) || (g + 4 * k) == c) continue;
+        dk[k] += pb.xp_info[(xe * 2 + ac) * D * D + (size_t)k_row[k] * D + kc];
+      }
+    }
+    // this block's share of the graph error: unary point of state i, the interpolated points and the
+    // GP prior of the interval ending at i, plus the owners' prior / limit / dynamics terms of state i
+    double err_acc = o_ee;
+    if (lane <= I && (lane == I || has_prev)) err_acc += si.pt(lane)[NG + D];
+    if (lane == 63 && has_prev) err_acc += si.gpr()[n];
+    // owners' values -> diagonal and rhs column (-g_i in column rhscol)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int rho = g + 4 * k, src = rho - row0;   // src = (lane >> 4) + 4 k, always a lane in 0..15
+      const double dsh = __shfl(o_dd, src, 64), gsh = __shfl(o_gg, src, 64);
+      double v = dk[k];
+      if (rho < n && c == rho) v += dsh;
+      if (rho < n && c == rhscol) v = -gsh;
+      S.r[k] = v;
+      Cr.r[k] = hrk[k];
+      Cl.r[k] = hlk[k];
     }
     return err_acc;
   }

@@ -94,7 +94,7 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
   });
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const double s = 1.0 / sqrt(piv_of_row[k]);
+    const double s = fast_rsqrt(piv_of_row[k]);
     const double y = S.r[k] * s;
     Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
     Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
@@ -114,7 +114,8 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
 #define G2_STAMP(k) do {} while (0)
 #endif
 #ifdef G2_STAMPS
-#define G2_ASTAMP(k) do { if (i == 1 && lane == 0) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G2_ASTAMP(k) do { if (i == 1 && lane == 0) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+                          if (i == 2 && lane == 0) pb.stamps[(size_t)b * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G2_ASTAMP(k) do {} while (0)
 #endif
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* _
   // the 4 blocks of the group need the 5 intervals 4q .. 4q+4; every interval is staged once, into a slot all
   // wavefronts can read: wavefront wv stages interval 4q + wv (the last one also 4q + 4) and then uses slots
   // wv (interval i) and wv + 1 (interval i + 1)
-  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.REC, P.GPREC);   // [2 odd blocks][Wl, Wr]
+  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.RECS, P.GPS);   // [2 odd blocks][Wl, Wr]
   const double* rec = rec_of(pb, pb.which[b], bufsel);
   const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* _
   }
   if (!fuse2) return;
   __syncthreads();
+  G2_ASTAMP(6);
   if (!lvl2) return;
   // level h = 2, block j = 4q + 2 (an odd multiple of 2): the E task of cr_forward with the
   // neighbours' factor tiles taken from LDS
@@ -254,13 +256,14 @@ __global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* _
     tile_store(f + TILE_DBL, C2r, lane);
     tile_store(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
+    G2_ASTAMP(7);
   }
 }
 
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st) {
   const dim3 grid(hp.B * ((hp.N + ASM_WAVES) / ASM_WAVES)), block(64 * ASM_WAVES);
-  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) + 4 * TILE_DBL) * sizeof(double);
+  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) + 4 * TILE_DBL) * sizeof(double);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
   case DD:                                                                                              \
@@ -339,19 +342,27 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   // level-2 updates of the surviving blocks (multiples of 4) were NOT applied there, so they are
   // absorbed together with the level-4 ones
   const int h0 = (N >= 2) ? 4 : 2;
+  // Level 4 would be 13 E + 13 U tasks on 16 wavefronts (two rounds) for N = 100: its U tasks (the blocks that
+  // are multiples of 8) are deferred -- at level 8 every task absorbs the Schur complements of its level-1,
+  // level-2 and level-4 neighbours in one go, so both levels take a single round.
+  const bool defer4 = (h0 == 4) && (hfinal >= 8);
   for (int h = h0; h <= hfinal; h <<= 1) {
     const bool final = (h == hfinal);
     const int hh = h >> 1;
     const int countE = final ? 1 : ((N / h) + 1) / 2;
-    const int countU = final ? 0 : (N / (2 * h)) + 1;  // multiples of 2h in [0, N]
+    const int countU = (final || (defer4 && h == 4)) ? 0 : (N / (2 * h)) + 1;  // multiples of 2h in [0, N]
     for (int idx = w; idx < countE + countU; idx += CR_WAVES) {
       const bool elim = idx < countE;
       const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
       Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
       Tile Cl = tile_zero(), Cr = tile_zero();
-      if (h == 4 && h0 == 4) {  // pending level-1 Schur complements of the odd neighbours
+      if (h0 == 4 && (h == 4 || (defer4 && h == 8))) {  // pending level-1 Schur complements of the odd neighbours
         if (j - 1 >= 0) schur_sub<n>(S, tile_load(fac + (size_t)(j - 1) * 3 * TILE_DBL + TILE_DBL, lane), lane);
         if (j + 1 <= N) schur_sub<n>(S, tile_load(fac + (size_t)(j + 1) * 3 * TILE_DBL, lane), lane);
+      }
+      if (defer4 && h == 8) {                           // ... and the level-2 ones deferred from level 4
+        if (j - 2 >= 0) schur_sub<n>(S, tile_load(fac + (size_t)(j - 2) * 3 * TILE_DBL + TILE_DBL, lane), lane);
+        if (j + 2 <= N) schur_sub<n>(S, tile_load(fac + (size_t)(j + 2) * 3 * TILE_DBL, lane), lane);
       }
       const int jm = j - hh, jp = j + hh;
       if (jm >= 0) {

@@ -12,6 +12,7 @@ constexpr int XP_MAX = GPMP2MI_MAX_STATE_PRIORS;  // extra per-state priors per 
 // Uniform parameters of a plan; lives in HBM, read through scalar loads.
 struct PlanParams {
   int B, N, I, P, Ppad, D, n, NG, REC, Npad, GPREC;
+  int RECS, GPS;                       // record strides in HBM and LDS: REC / GPREC rounded up to even (16-B pieces)
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
@@ -22,7 +23,11 @@ struct PlanParams {
   double vdyn_w;                       // 1 / dynamics_sigma^2 or 0
   double rel_thresh, abs_tol, err_tol;
   double lm_lambda0, lm_factor, lm_upper, lm_lower, lm_min_fidelity, dl_delta0;
-  GpCoef coef[MAXI];
+  alignas(16) GpCoef coef[MAXI];
+  // per sub-step, for the assembler (staged into LDS): [0..3] Psi_r Psi_c, [4..7] Lam_r Lam_c, [8..11] Lam_r Psi_c,
+  // [12..15] Psi_r Lam_c at index ar * 2 + ac (a = 0 conf / 1 vel; Lam = (l11, l12), Psi = (p11, p12)); [16..19]
+  // l11 l12 p11 p12; rest padding
+  alignas(16) double coefq[MAXI][24];
   double Winv[4];                      // B(delta_t): 12/dt^3, -6/dt^2, -6/dt^2, 4/dt
   double Qc_inv[MAXD * MAXD];
   double pos_lo[MAXD], pos_hi[MAXD], pos_th[MAXD], pos_w[MAXD];
@@ -44,9 +49,9 @@ struct PlanBuffers {
   double* trial;           // [B][N+1][2D]  LM / Dogleg trial point
   double* init;            // [B][N+1][2D]  pristine initial values (optimize() can be re-run)
   double* result;          // [B][N+1][2D]
-  double* rec;             // [B][REC][Ppad] per-point G (packed upper), g, e   (buffer 0)
+  double* rec;             // [B][Ppad][RECS] point-major records: G (packed upper), g, e [, M1..M4]   (buffer 0)
   double* rec2;            // second buffer for trial linearizations (LM / Dogleg)
-  double* gpu;             // [B][n+1][Npad] GP prior W r (n) and r^T W r, per interval end state
+  double* gpu;             // [B][Npad][GPS] per interval end state: GP prior u = W r (n), r^T W r [, J1, J3]
   double* gpu2;
   double* tiles;           // [B][N+1][256] diagonal tile S_i = [D_i | -g_i] of every even block (updated in place)
   double* fac;             // [B][N+1][3][256] factor tiles Wl, Wr (both carry y), V = R^-T

@@ -72,11 +72,11 @@ __device__ __forceinline__ double total_error(const PlanParams& P, const PlanBuf
                                               const double* __restrict__ tr,
                                               const double* __restrict__ rec,
                                               const double* __restrict__ gpu, int lane) {
-  const double* eb = rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+  const double* eb = rec + (size_t)b * P.Ppad * P.RECS + (P.NG + P.D);
   double acc = 0.0;
-  for (int p = lane; p < P.P; p += 64) acc += eb[p];
-  const double* gb = gpu + ((size_t)b * P.GPREC + P.n) * P.Npad;
-  for (int i = 1 + lane; i <= P.N; i += 64) acc += gb[i];
+  for (int p = lane; p < P.P; p += 64) acc += eb[(size_t)p * P.RECS];
+  const double* gb = gpu + (size_t)b * P.Npad * P.GPS + P.n;
+  for (int i = 1 + lane; i <= P.N; i += 64) acc += gb[(size_t)i * P.GPS];
   return 0.5 * (wave_sum(acc) + misc_error(P, pb, b, tr, lane));
 }
 
@@ -85,11 +85,11 @@ __device__ __forceinline__ double total_error(const PlanParams& P, const PlanBuf
 __device__ __forceinline__ double total_error_partial(const PlanParams& P, const PlanBuffers& pb, int b,
                                                       const double* __restrict__ tr, const double* __restrict__ rec,
                                                       const double* __restrict__ gpu, int tid, int nthr) {
-  const double* eb = rec + ((size_t)b * P.REC + (P.NG + P.D)) * P.Ppad;
+  const double* eb = rec + (size_t)b * P.Ppad * P.RECS + (P.NG + P.D);
   double acc = 0.0;
-  for (int p = tid; p < P.P; p += nthr) acc += eb[p];
-  const double* gb = gpu + ((size_t)b * P.GPREC + P.n) * P.Npad;
-  for (int i = 1 + tid; i <= P.N; i += nthr) acc += gb[i];
+  for (int p = tid; p < P.P; p += nthr) acc += eb[(size_t)p * P.RECS];
+  const double* gb = gpu + (size_t)b * P.Npad * P.GPS + P.n;
+  for (int i = 1 + tid; i <= P.N; i += nthr) acc += gb[(size_t)i * P.GPS];
   return acc + misc_error_partial(P, pb, b, tr, tid, nthr);
 }
 

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   }
   __syncthreads();
   if (p_raw >= P.P) return;
-  G2_LSTAMP(2);
+  G2_LSTAMP(1);
   double G[NG], gv[D], e = 0.0;
 #pragma unroll
   for (int k = 0; k < NG; k++) G[k] = 0.0;
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     K::visit_spheres(
         R, q,
         [&](int s, const double (&pt)[3]) {
+          if (s < 11) G2_LSTAMP(2 + s);
           r = hinge_obstacle<SDIM>(sdf, pt[0], pt[1], pt[2], R.sph_r[s] + eps, hx, hy, hz);
           // inactive hinge (or out of the field): zero residual row, nothing to accumulate --
           // and the sphere's Jacobian is never formed
@@ -130,24 +131,32 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
         },
         [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) { accumulate(Jc, nc); });
   }
-  G2_LSTAMP(5);
+  G2_LSTAMP(13);
   const double w = P.obs_w;
-  double* rb = rec + (size_t)b * P.REC * P.Ppad + p;
+  // point-major record: this lane's REC values are one contiguous run, stored in 16-B pieces
+  {
+    constexpr int RECL = NG + D + 1 + (K::BASE == 3 ? 36 : 0);
+    double rv[RECL + 1];
 #pragma unroll
-  for (int k = 0; k < NG; k++) rb[(size_t)k * P.Ppad] = G[k] * w;
+    for (int k = 0; k < NG; k++) rv[k] = G[k] * w;
 #pragma unroll
-  for (int k = 0; k < D; k++) rb[(size_t)(NG + k) * P.Ppad] = gv[k] * w;
-  rb[(size_t)(NG + D) * P.Ppad] = e * w;
-  if constexpr (K::BASE == 3) {
-    if (P.REC > NG + D + 1) {  // pose blocks of the four interpolation Jacobians
+    for (int k = 0; k < D; k++) rv[NG + k] = gv[k] * w;
+    rv[NG + D] = e * w;
+    if constexpr (K::BASE == 3) {  // pose blocks of the four interpolation Jacobians
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int t = 0; t < 9; t++) rb[(size_t)(NG + D + 1 + m * 9 + t) * P.Ppad] = lie_interp ? Mlie[m][t] : 0.0;
+        for (int t = 0; t < 9; t++) rv[NG + D + 1 + m * 9 + t] = lie_interp ? Mlie[m][t] : 0.0;
     }
+    rv[RECL] = 0.0;
+    double2* rb = reinterpret_cast<double2*>(rec + ((size_t)b * P.Ppad + p) * P.RECS);
+    const int nst = P.RECS >> 1;   // REC <= RECL: mobile robots without interpolation store the short record
+#pragma unroll
+    for (int k = 0; k < (RECL + 1) / 2; k++)
+      if (k < nst) rb[k] = double2{rv[2 * k], rv[2 * k + 1]};
   }
 
-  G2_LSTAMP(6);
+  G2_LSTAMP(14);
   // GP prior of the interval ending at state i.  Vector spaces: GaussianProcessPriorLinear
   // (gp/GaussianProcessPriorLinear.h:57-83) r = Phi z_{i-1} - z_i.  Pose2 robots:
   // GaussianProcessPriorLie<Pose2Vector> (gp/GaussianProcessPriorLie.h:61-86)
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   // Both: u = Q^-1 r (Q^-1 = B(dt) (x) Qc^-1), energy r^T u.
   if (unary && i > 0) {
     double rx[D], rv[D], sx[D], sv[D];
-    double* gb = gpu + (size_t)b * P.GPREC * P.Npad + i;
+    double* gb = gpu + ((size_t)b * P.Npad + i) * P.GPS;
     if constexpr (K::BASE == 3) {
       const P2 p1{x0[0], x0[1], x0[2]}, p2{x1[0], x1[1], x1[2]};
       const P2 bt = pose2_between(p1, p2);
@@ -168,8 +177,8 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
       mat3_mul(T, Hinv, J1);
 #pragma unroll
       for (int k = 0; k < 9; k++) {
-        gb[(size_t)(n + 1 + k) * P.Npad] = -J1[k];
-        gb[(size_t)(n + 1 + 9 + k) * P.Npad] = Hlog[k];
+        gb[n + 1 + k] = -J1[k];
+        gb[n + 1 + 9 + k] = Hlog[k];
       }
 #pragma unroll
       for (int k = 0; k < D; k++) {
@@ -200,13 +209,13 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     for (int k = 0; k < D; k++) {
       const double ux = P.Winv[0] * sx[k] + P.Winv[1] * sv[k];
       const double uv = P.Winv[2] * sx[k] + P.Winv[3] * sv[k];
-      gb[(size_t)k * P.Npad] = ux;
-      gb[(size_t)(D + k) * P.Npad] = uv;
+      gb[k] = ux;
+      gb[D + k] = uv;
       en += rx[k] * ux + rv[k] * uv;
     }
-    gb[(size_t)n * P.Npad] = en;
+    gb[n] = en;
   }
-  G2_LSTAMP(7);
+  G2_LSTAMP(15);
 }
 
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                             double* Hd, double* Ho, double* g, hipStream_t st, const int* active) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
-  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
+  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) * sizeof(double);
   switch (hp.D) {
 #define G2_EXP_CASE(DD) \
   case DD:                                                                                          \

@@ -31,6 +31,20 @@ __device__ __forceinline__ double fast_rcp(double x) {
   return r;
 }
 
+// 1 / sqrt(x): v_rsq_f64 seed (~2^-23 relative) + two Newton steps (error below 1 ulp before the final
+// roundings) instead of a full-precision sqrt followed by a full-precision division (~35 vs 9 instructions;
+// four of them close every tile elimination).
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double t = x * y;
+    const double e = fma(-t, y, 1.0);
+    y = fma(0.5 * y, e, y);
+  }
+  return y;
+}
+
 // =============================================================================== cross-lane moves
 // All VALU (no LDS): gfx950 v_permlane16_swap / v_permlane32_swap for moves between the four
 // 16-lane rows of a wavefront, DPP row_newbcast / row_ror for moves inside a row.

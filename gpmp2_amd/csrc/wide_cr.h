@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64) void k_assemble_wide(const PlanParams* __restri
 int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                          const int* active, hipStream_t st) {
   const dim3 grid(hp.B * (hp.N + 1)), block(64);
-  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.REC + hp.GPREC) * sizeof(double);
+  const size_t shmem = 2 * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) * sizeof(double);
   switch (hp.D) {
 #define G2_ASMW_CASE(DD) \
   case DD:                                                                                      \
