@@ -328,7 +328,8 @@ constexpr int CR_WAVES = G2_CR_WAVES;
 // All CR_WAVES wavefronts of the workgroup take part; returns false (per wavefront) on a bad pivot.
 template <int n>
 __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, int tid) {
-  const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  // (wavefront index as a scalar: the task selection below then compiles to scalar branches)
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   // ---- forward: block cyclic reduction.  Level h = 1 (odd blocks) was done by k_assemble.
   // Phase h >= 2: every block that is still active (multiple of h) absorbs the Schur complements
   // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
@@ -354,33 +355,36 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
     for (int idx = w; idx < countE + countU; idx += CR_WAVES) {
       const bool elim = idx < countE;
       const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
-      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
-      Tile Cl = tile_zero(), Cr = tile_zero();
-      if (h0 == 4 && (h == 4 || (defer4 && h == 8))) {  // pending level-1 Schur complements of the odd neighbours
-        if (j - 1 >= 0) schur_sub<n>(S, tile_load(fac + (size_t)(j - 1) * 3 * TILE_DBL + TILE_DBL, lane), lane);
-        if (j + 1 <= N) schur_sub<n>(S, tile_load(fac + (size_t)(j + 1) * 3 * TILE_DBL, lane), lane);
-      }
-      if (defer4 && h == 8) {                           // ... and the level-2 ones deferred from level 4
-        if (j - 2 >= 0) schur_sub<n>(S, tile_load(fac + (size_t)(j - 2) * 3 * TILE_DBL + TILE_DBL, lane), lane);
-        if (j + 2 <= N) schur_sub<n>(S, tile_load(fac + (size_t)(j + 2) * 3 * TILE_DBL, lane), lane);
-      }
+      // every tile this task needs is requested before the first product: the level-1 / level-2 factors come from
+      // the previous kernel (other XCDs' L2 -> Infinity Cache / HBM latency), and one latency is paid instead of
+      // one per neighbour
+      const bool p1 = h0 == 4 && (h == 4 || (defer4 && h == 8));   // pending level-1 Schur complements
+      const bool p2 = defer4 && h == 8;                             // ... and the level-2 ones deferred from level 4
       const int jm = j - hh, jp = j + hh;
-      if (jm >= 0) {
-        const Tile Wr = tile_load(fac + (size_t)jm * 3 * TILE_DBL + TILE_DBL, lane);
-        schur_sub<n>(S, Wr, lane);
-        if (elim && !final) {
-          const Tile Wl = tile_load(fac + (size_t)jm * 3 * TILE_DBL, lane);
-          Cl = coupling<n>(Wr, Wl, lane);  // rows j, cols j - h
-        }
-      }
-      if (jp <= N) {
-        const Tile Wl = tile_load(fac + (size_t)jp * 3 * TILE_DBL, lane);
-        schur_sub<n>(S, Wl, lane);
-        if (elim && !final && j + h <= N) {
-          const Tile Wr = tile_load(fac + (size_t)jp * 3 * TILE_DBL + TILE_DBL, lane);
-          Cr = coupling<n>(Wl, Wr, lane);  // rows j, cols j + h
-        }
-      }
+      const bool e1m = p1 && j - 1 >= 0, e1p = p1 && j + 1 <= N, e2m = p2 && j - 2 >= 0, e2p = p2 && j + 2 <= N;
+      const bool em = jm >= 0, ep = jp <= N;
+      const bool cm = em && elim && !final, cp = ep && elim && !final && j + h <= N;
+      auto facp = [&](int blk, int which) { return fac + ((size_t)blk * 3 + which) * TILE_DBL; };
+      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
+      Tile T1m = tile_zero(), T1p = tile_zero(), T2m = tile_zero(), T2p = tile_zero();
+      Tile Wr_m = tile_zero(), Wl_m = tile_zero(), Wl_p = tile_zero(), Wr_p = tile_zero();
+      if (e1m) T1m = tile_load(facp(j - 1, 1), lane);
+      if (e1p) T1p = tile_load(facp(j + 1, 0), lane);
+      if (e2m) T2m = tile_load(facp(j - 2, 1), lane);
+      if (e2p) T2p = tile_load(facp(j + 2, 0), lane);
+      if (em) Wr_m = tile_load(facp(jm, 1), lane);
+      if (cm) Wl_m = tile_load(facp(jm, 0), lane);
+      if (ep) Wl_p = tile_load(facp(jp, 0), lane);
+      if (cp) Wr_p = tile_load(facp(jp, 1), lane);
+      Tile Cl = tile_zero(), Cr = tile_zero();
+      if (e1m) schur_sub<n>(S, T1m, lane);
+      if (e1p) schur_sub<n>(S, T1p, lane);
+      if (e2m) schur_sub<n>(S, T2m, lane);
+      if (e2p) schur_sub<n>(S, T2p, lane);
+      if (em) schur_sub<n>(S, Wr_m, lane);
+      if (cm) Cl = coupling<n>(Wr_m, Wl_m, lane);  // rows j, cols j - h
+      if (ep) schur_sub<n>(S, Wl_p, lane);
+      if (cp) Cr = coupling<n>(Wl_p, Wr_p, lane);  // rows j, cols j + h
       if (!elim) {
         tile_store(tiles + (size_t)j * TILE_DBL, S, lane);
         continue;
@@ -404,7 +408,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
 // xs[(N+1)][16] (LDS).
 template <int n>
 __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs, int hmin = 1) {
-  const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
