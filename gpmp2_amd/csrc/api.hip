@@ -1367,6 +1367,15 @@ int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64)
   return GPMP2MI_OK;
 }
 
+// diagnostic: the scalars of trajectory b's last trial step (PlanBuffers::scal, see plan.h SC_*) and its
+// current lambda / trust radius in out[16]
+int gpmp2mi_plan_debug_scalars(gpmp2mi_plan* p, int b, double* out17) {
+  G2_CHECK(p && out17 && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_HIP(hipMemcpy(out17, p->pb.scal + (size_t)b * SC_COUNT, SC_COUNT * sizeof(double), hipMemcpyDeviceToHost));
+  G2_HIP(hipMemcpy(out17 + SC_COUNT, p->pb.lambda + b, sizeof(double), hipMemcpyDeviceToHost));
+  return GPMP2MI_OK;
+}
+
 // diagnostic: out[8][64] = {bcast_row<0..3>, bcast_in_row<5>, row_sum16, sum_rows, bcast_in_row<13>}(in[64])
 int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
   G2_CHECK(in64 && out512, GPMP2MI_ERR_INVALID, "null argument");

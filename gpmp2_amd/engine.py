@@ -377,6 +377,11 @@ class Plan:
     def update(self, iterations=1, stream=None):
         self.eng._ck(self.eng.lib.gpmp2mi_plan_update(self.h.ptr, int(iterations), C.c_void_p(stream or 0)))
 
+    def debug_scalars(self, b):
+        out = np.zeros(17)
+        self.eng._ck(self.eng.lib.gpmp2mi_plan_debug_scalars(self.h.ptr, int(b), dptr(out)))
+        return dict(gd=out[0], dd=out[1], gg=out[2], ghg=out[3], gn=out[4], nn=out[5], q=out[6], xnorm=out[7], radius=out[16])
+
     def enable_timing(self, on=True):
         self.eng._ck(self.eng.lib.gpmp2mi_plan_enable_timing(self.h.ptr, int(on)))
 

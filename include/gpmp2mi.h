@@ -395,6 +395,9 @@ int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable);
 int gpmp2mi_plan_get_timing(gpmp2mi_plan* p, int* n, const char** names, double* ms, int* launches);
 /* Diagnostic builds (-DG2_STAMPS) only: 64 raw s_memtime stamps of trajectory b's last solve step. */
 int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64);
+/* Diagnostic: scalars of trajectory b's last LM / Dogleg trial step, out17 = {g.delta, |delta|^2, g.g, g^T H g,
+ * g.dx_n, |dx_n|^2, model decrease q, |step|, zero-step flag, -, ..., [16] = current lambda / trust radius}. */
+int gpmp2mi_plan_debug_scalars(gpmp2mi_plan* p, int b, double* out17);
 /* Test hook, host only (no GPU needed): the wall-clock-bounded spin the pass driver uses on its device-mapped
  * pass flags, run on a caller-owned flag: returns GPMP2MI_OK with *value = *flag once *flag >= 0, or
  * GPMP2MI_ERR_HIP (gpmp2mi_last_error set) after timeout_ms.  The driver's own limit is 5 s

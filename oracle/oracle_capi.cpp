@@ -469,6 +469,12 @@ int orc_batch_optimize_xp(const void* r, const void* s, const gpmp2mi_settings* 
   return 0;
 }
 
+int orc_set_dogleg_probe(double* buf, int cap_rows) {
+  set_dogleg_probe(buf, cap_rows);
+  return 0;
+}
+int orc_dogleg_probe_rows() { return dogleg_probe_rows(); }
+
 int orc_collision_cost(const void* r, const void* s, int total_step, int B, const double* traj,
                        double* cost) {
   // internal::CollisionCost  planner/BatchTrajOptimizer-inl.h:87-100 (epsilon = 0)

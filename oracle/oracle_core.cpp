@@ -1506,6 +1506,17 @@ static void iterate_lm(const Problem& P, State& st) {
   }
 }
 
+// test probe: when set, every Dogleg trial point appends {gg, gHg, g.dx_n, |dx_n|^2, |dx_u|^2, dx_u.dx_n, tau,
+// Delta, rho, new_f} (tau = -1 outside the blend branch).  Single-threaded use only (tests/, scripts/).
+static double* g_dl_probe = nullptr;
+static int g_dl_probe_cap = 0, g_dl_probe_n = 0;
+void set_dogleg_probe(double* buf, int cap_rows) {
+  g_dl_probe = buf;
+  g_dl_probe_cap = cap_rows;
+  g_dl_probe_n = 0;
+}
+int dogleg_probe_rows() { return g_dl_probe_n; }
+
 static void iterate_dogleg(const Problem& P, State& st) {
   // DoglegOptimizer::iterate + DoglegOptimizerImpl::Iterate(ONE_STEP_PER_ITERATION)
   std::vector<LinFactor> F;
@@ -1541,6 +1552,7 @@ static void iterate_dogleg(const Problem& P, State& st) {
       un += dx_u[i] * dx_n[i];
     }
     const double DeltaSq = delta * delta;
+    double tau_used = -1.0;
     if (DeltaSq < uu) {
       const double k = std::sqrt(DeltaSq / uu);
       for (size_t i = 0; i < m; i++) dx_d[i] = k * dx_u[i];
@@ -1549,6 +1561,7 @@ static void iterate_dogleg(const Problem& P, State& st) {
       const double sq = std::sqrt(b * b - 4 * a * c);
       const double tau1 = (-b + sq) / (2. * a), tau2 = (-b - sq) / (2. * a);
       const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
+      tau_used = tau;
       for (size_t i = 0; i < m; i++) dx_d[i] = (1. - tau) * dx_u[i] + tau * dx_n[i];
     } else {
       dx_d = dx_n;
@@ -1559,6 +1572,14 @@ static void iterate_dogleg(const Problem& P, State& st) {
     const double rho = (std::fabs(f_error - new_f) < 1e-15 || std::fabs(M_error - new_M) < 1e-15)
                            ? 0.5
                            : (f_error - new_f) / (M_error - new_M);
+    if (g_dl_probe && g_dl_probe_n < g_dl_probe_cap) {
+      double gn = 0;
+      for (size_t i = 0; i < m; i++) gn += ne.g[i] * dx_n[i];
+      double* row = g_dl_probe + (size_t)g_dl_probe_n * 10;
+      const double vals[10] = {gg, gHg, gn, nn, uu, un, tau_used, delta, rho, new_f};
+      for (int k = 0; k < 10; k++) row[k] = vals[k];
+      g_dl_probe_n++;
+    }
     if (rho >= 0.75) {
       double dn = 0;
       for (size_t i = 0; i < m; i++) dn += dx_d[i] * dx_d[i];

@@ -217,5 +217,8 @@ struct OptResult {
 };
 // gpmp2::optimize (planner/BatchTrajOptimizer.cpp:212-308) with GTSAM GN / LM / Dogleg semantics
 OptResult optimize(const Problem& P, const double* init, double* out);
+// test probe of the Dogleg trial points (see oracle_core.cpp); buf = nullptr switches it off
+void set_dogleg_probe(double* buf, int cap_rows);
+int dogleg_probe_rows();
 
 }  // namespace orc

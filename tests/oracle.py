@@ -259,6 +259,23 @@ class Oracle:
                                     iptr(status), dptr(trace), int(nthreads))
         return dict(traj=out, iters=iters, final_error=ferr, status=status, error_trace=trace)
 
+    def dogleg_probe(self, rows=256):
+        """context manager: records {gg, gHg, g.dx_n, |dx_n|^2, |dx_u|^2, dx_u.dx_n, tau, Delta, rho, new_f} of every
+        Dogleg trial point of the solves run inside it (single-threaded solves only)"""
+        orc = self
+
+        class _Probe:
+            def __enter__(self_):
+                self_.buf = np.zeros((rows, 10))
+                orc.lib.orc_set_dogleg_probe(dptr(self_.buf), rows)
+                return self_
+
+            def __exit__(self_, *a):
+                self_.rows = self_.buf[: orc.lib.orc_dogleg_probe_rows()].copy()
+                orc.lib.orc_set_dogleg_probe(None, 0)
+
+        return _Probe()
+
     def batch_optimize_xp(self, robot, sdf, setting, start_conf, start_vel, end_conf, end_vel, init, priors, goal_on):
         """priors: per trajectory a list of dicts(state, conf, Wc, vel=None, Wv=None); goal_on: [B] ints."""
         s, o, keep = _capi.make_settings(setting)
