@@ -45,13 +45,26 @@ class Settings(C.Structure):
                 ("max_iter", C.c_int)]
 
 
+MAX_WORKSPACE_FACTORS, MAX_SELF_COLLISION_PAIRS = 4, 16
+WORKSPACE_POSITION, WORKSPACE_ORIENTATION, WORKSPACE_POSE = 0, 1, 2
+
+
+class WorkspaceFactor(C.Structure):
+    _fields_ = [("mode", C.c_int), ("link", C.c_int), ("first_state", C.c_int), ("last_state", C.c_int),
+                ("sigma", C.c_double), ("des_pose", C.c_double * 16)]
+
+
 class GraphOpts(C.Structure):
     _fields_ = [("obs_skip_first_state", C.c_int), ("vehicle_dynamics_sigma", C.c_double),
                 ("lm_lambda_initial", C.c_double), ("lm_lambda_factor", C.c_double),
                 ("lm_lambda_upper", C.c_double), ("lm_lambda_lower", C.c_double),
                 ("lm_min_model_fidelity", C.c_double), ("dogleg_delta_initial", C.c_double),
                 ("abs_error_tol", C.c_double), ("error_tol", C.c_double),
-                ("fixed_iterations", C.c_int)]
+                ("fixed_iterations", C.c_int),
+                ("end_conf_prior_off", C.c_int), ("n_workspace", C.c_int),
+                ("workspace", WorkspaceFactor * MAX_WORKSPACE_FACTORS),
+                ("n_self_collision", C.c_int), ("self_collision_first", C.c_int), ("self_collision_last", C.c_int),
+                ("self_collision", (C.c_double * 4) * MAX_SELF_COLLISION_PAIRS)]
 
 
 def dptr(a):
@@ -140,4 +153,27 @@ def make_settings(setting):
     o.dogleg_delta_initial = setting.dogleg_delta_initial
     o.abs_error_tol, o.error_tol = setting.abs_error_tol, setting.error_tol
     o.fixed_iterations = setting.fixed_iterations
+    o.end_conf_prior_off = int(getattr(setting, "end_conf_prior_off", False))
+    ws = list(getattr(setting, "workspace_factors", []) or [])
+    if len(ws) > MAX_WORKSPACE_FACTORS:
+        raise ValueError("too many workspace factors for one plan")
+    o.n_workspace = len(ws)
+    for k, w in enumerate(ws):
+        o.workspace[k].mode, o.workspace[k].link = int(w["mode"]), int(w["link"])
+        o.workspace[k].first_state, o.workspace[k].last_state = int(w["first_state"]), int(w["last_state"])
+        o.workspace[k].sigma = float(w["sigma"])
+        des = f64(w["des_pose"]).reshape(16)
+        for t in range(16):
+            o.workspace[k].des_pose[t] = des[t]
+    sc = getattr(setting, "self_collision", None)
+    if sc is not None:
+        sc = f64(sc).reshape(-1, 4)
+        if sc.shape[0] > MAX_SELF_COLLISION_PAIRS:
+            raise ValueError("too many self-collision pairs for one plan")
+        o.n_self_collision = sc.shape[0]
+        rng_ = getattr(setting, "self_collision_states", None) or (0, setting.total_step)
+        o.self_collision_first, o.self_collision_last = int(rng_[0]), int(rng_[1])
+        for k in range(sc.shape[0]):
+            for t in range(4):
+                o.self_collision[k][t] = sc[k, t]
     return s, o, keep

@@ -226,12 +226,37 @@ struct gpmp2mi_plan {
   bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
   int n_active_len = 0;
   std::vector<int> h_xp_n;   // host mirror of the extra-prior counts
+  PlanExtras ex;             // extra factors carried as data (host copy of the specs + device workspace)
+  bool has_extras = false;
   bool problem_set = false;
   bool optimized = false;
   size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
 };
 
 static int plan_run(gpmp2mi_plan* p, hipStream_t st);
+
+// linearize `traj` into record buffer `bufsel` of every (active) trajectory: the fused obstacle / GP-prior kernel,
+// then -- only for plans that carry extra factors -- the workspace / self-collision factor kernels on the support
+// states and their accumulation into the unary records
+static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st) {
+  const PlanParams& P = p->hp;
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st));
+  if (!p->has_extras) return GPMP2MI_OK;
+  const PlanExtras& ex = p->ex;
+  const RobotDev& h = p->robot->h;
+  const int M = P.B * (P.N + 1), D = P.D, L = h.nr_links, S = h.nr_spheres;
+  if (ex.n_ws > 0) {
+    G2_TRY(launch_fk(h, p->robot->d, M, traj, ex.poses, ex.Jp, st, 2 * D));
+    for (int f = 0; f < ex.n_ws; f++)
+      G2_TRY(launch_workspace_prior(ex.ws_mode[f], ex.ws_link[f], L, D, M, ex.des + 16 * f, ex.poses, ex.Jp,
+                                    ex.ws_err + (size_t)f * M * 6, ex.ws_H + (size_t)f * M * 6 * D, st));
+  }
+  if (ex.n_sc > 0) {
+    G2_TRY(launch_sphere_centers(h, p->robot->d, M, traj, ex.cen, ex.Jc, st, 2 * D));
+    G2_TRY(launch_self_collision(ex.n_sc, S, D, M, ex.sc_data, ex.radius, ex.cen, ex.Jc, ex.sc_err, ex.sc_H, st));
+  }
+  return launch_extra_accumulate(P, p->pb, ex, L, S, bufsel, active, st);
+}
 
 template <class T>
 static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
@@ -859,6 +884,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.max_iter = s->max_iter;
   P.no_increase = s->final_iter_no_increase;
   P.fixed_iters = o.fixed_iterations;
+  P.end_conf_prior_off = o.end_conf_prior_off ? 1 : 0;
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
   // planner/BatchTrajOptimizer-inl.h:30-31
@@ -989,6 +1015,66 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     p->n_active_len = cap * mult + 3;
     P.max_pass = p->n_active_len;
   }
+  // ---- extra factors as data
+  {
+    PlanExtras& ex = p->ex;
+    std::memset(&ex, 0, sizeof(ex));
+    G2_CHECK(o.n_workspace >= 0 && o.n_workspace <= GPMP2MI_MAX_WORKSPACE_FACTORS, GPMP2MI_ERR_INVALID, "too many workspace factors");
+    G2_CHECK(o.n_self_collision >= 0 && o.n_self_collision <= GPMP2MI_MAX_SELF_COLLISION_PAIRS, GPMP2MI_ERR_INVALID,
+             "too many self-collision pairs");
+    const RobotDev& h = robot->h;
+    const size_t M = (size_t)B * (P.N + 1);
+    ex.n_ws = o.n_workspace;
+    ex.n_sc = o.n_self_collision;
+    std::vector<double> des(16 * std::max(ex.n_ws, 1)), scd(4 * std::max(ex.n_sc, 1)), radius(std::max(h.nr_spheres, 1));
+    for (int f = 0; f < ex.n_ws; f++) {
+      const gpmp2mi_workspace_factor& w = o.workspace[f];
+      G2_CHECK(w.mode >= GPMP2MI_WORKSPACE_POSITION && w.mode <= GPMP2MI_WORKSPACE_POSE, GPMP2MI_ERR_INVALID, "unknown workspace factor mode");
+      G2_CHECK(w.link >= 0 && w.link < h.nr_links, GPMP2MI_ERR_INVALID, "workspace factor: link out of range");
+      G2_CHECK(w.sigma > 0, GPMP2MI_ERR_INVALID, "workspace factor: sigma must be positive");
+      G2_CHECK(w.first_state >= 0 && w.first_state <= w.last_state && w.last_state <= P.N, GPMP2MI_ERR_INVALID,
+               "workspace factor: bad state range");
+      ex.ws_mode[f] = w.mode;
+      ex.ws_link[f] = w.link;
+      ex.ws_first[f] = w.first_state;
+      ex.ws_last[f] = w.last_state;
+      ex.ws_w[f] = 1.0 / (w.sigma * w.sigma);
+      std::copy(w.des_pose, w.des_pose + 16, des.begin() + 16 * f);
+    }
+    if (ex.n_sc > 0) {
+      G2_CHECK(o.self_collision_first >= 0 && o.self_collision_first <= o.self_collision_last && o.self_collision_last <= P.N,
+               GPMP2MI_ERR_INVALID, "self collision: bad state range");
+      ex.sc_first = o.self_collision_first;
+      ex.sc_last = o.self_collision_last;
+      for (int k = 0; k < ex.n_sc; k++) {
+        const double a = o.self_collision[k][0], bb = o.self_collision[k][1], sg = o.self_collision[k][3];
+        G2_CHECK(a >= 0 && a < h.nr_spheres && bb >= 0 && bb < h.nr_spheres, GPMP2MI_ERR_INVALID, "self collision: sphere id out of range");
+        G2_CHECK(sg > 0, GPMP2MI_ERR_INVALID, "self collision: sigma must be positive");
+        for (int t = 0; t < 4; t++) scd[4 * k + t] = o.self_collision[k][t];
+        ex.sc_w[k] = 1.0 / (sg * sg);
+      }
+      for (int sidx = 0; sidx < h.nr_spheres; sidx++) radius[h.sph_orig[sidx]] = h.sph_r[sidx];
+    }
+    p->has_extras = ex.n_ws > 0 || ex.n_sc > 0;
+    if (ex.n_ws > 0) {
+      G2_TRY(plan_alloc(p.get(), &ex.des, des.size()));
+      G2_HIP(hipMemcpy(ex.des, des.data(), des.size() * sizeof(double), hipMemcpyHostToDevice));
+      G2_TRY(plan_alloc(p.get(), &ex.poses, M * h.nr_links * 16));
+      G2_TRY(plan_alloc(p.get(), &ex.Jp, M * h.nr_links * 6 * D));
+      G2_TRY(plan_alloc(p.get(), &ex.ws_err, (size_t)ex.n_ws * M * 6));
+      G2_TRY(plan_alloc(p.get(), &ex.ws_H, (size_t)ex.n_ws * M * 6 * D));
+    }
+    if (ex.n_sc > 0) {
+      G2_TRY(plan_alloc(p.get(), &ex.sc_data, scd.size()));
+      G2_HIP(hipMemcpy(ex.sc_data, scd.data(), scd.size() * sizeof(double), hipMemcpyHostToDevice));
+      G2_TRY(plan_alloc(p.get(), &ex.radius, radius.size()));
+      G2_HIP(hipMemcpy(ex.radius, radius.data(), radius.size() * sizeof(double), hipMemcpyHostToDevice));
+      G2_TRY(plan_alloc(p.get(), &ex.cen, M * h.nr_spheres * 3));
+      G2_TRY(plan_alloc(p.get(), &ex.Jc, M * h.nr_spheres * 3 * D));
+      G2_TRY(plan_alloc(p.get(), &ex.sc_err, M * ex.n_sc));
+      G2_TRY(plan_alloc(p.get(), &ex.sc_H, M * ex.n_sc * D));
+    }
+  }
   G2_TRY(plan_alloc(p.get(), &pb.n_active, p->n_active_len));
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
   G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
@@ -1095,7 +1181,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
     const int max_pass = iter_cap + 1;
     for (int pass = 0; pass < max_pass; pass++) {
       p->timer.begin("linearize", st);
-      G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, 0, pb.active, st));
+      G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
       p->timer.begin("assemble", st);
       G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
       p->timer.begin("gn_step_cr", st);
@@ -1117,7 +1203,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
     // LM may retry an iterate with a larger lambda, Dogleg with a smaller radius, hence the cap.
     const int max_pass = p->n_active_len - 1;
     p->timer.begin("linearize", st);
-    G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.cur, 0, pb.active, st));
+    G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
     p->timer.begin("decide", st);
     G2_TRY(launch_decide(P, pb, 0, true, st));
     p->timer.close(st);
@@ -1149,7 +1235,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
         G2_TRY(launch_solve_step(P, pb, st));
       }
       p->timer.begin("linearize", st);
-      G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, pb.trial, 1, pb.active, st));
+      G2_TRY(plan_linearize(p, pb.trial, 1, pb.active, st));
       p->timer.begin("decide", st);
       G2_TRY(launch_decide(P, pb, pass, false, st));
       p->timer.close(st);
@@ -1202,7 +1288,7 @@ int gpmp2mi_plan_graph_error(gpmp2mi_plan* p, const double* traj, double* err) {
   DevBuf<double> dt, de;
   G2_TRY(dt.upload(traj, p->tsz()));
   G2_TRY(de.alloc(p->hp.B));
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, p->hp, p->pb, dt.p, 1, nullptr, nullptr));
+  G2_TRY(plan_linearize(p, dt.p, 1, nullptr, nullptr));
   G2_TRY(launch_error_reduce(p->hp, p->pb, dt.p, 1, de.p, nullptr));
   G2_HIP(hipDeviceSynchronize());
   G2_TRY(de.download(err));
@@ -1222,7 +1308,7 @@ int gpmp2mi_plan_linearize(gpmp2mi_plan* p, const double* traj, double* Hdiag, d
   if (err) G2_TRY(de.alloc(P.B));
   // evaluate into the spare record buffer (the one that does not hold the linearization at `cur`)
   const PlanBuffers& pb = p->pb;
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, pb, dt.p, 1, nullptr, nullptr));
+  G2_TRY(plan_linearize(p, dt.p, 1, nullptr, nullptr));
   G2_TRY(launch_export_normal_eq(P, pb, dt.p, 1, dd.p, dob.p, dg.p, nullptr));
   if (err) G2_TRY(launch_error_reduce(P, pb, dt.p, 1, de.p, nullptr));
   G2_HIP(hipDeviceSynchronize());

@@ -198,7 +198,8 @@ struct Assembler {
     double o_dd = 0.0, o_gg = 0.0, o_ee = 0.0;
     if (owner) {
       const int rho = orow, ar = rho >= D, kr = rho - ar * D;
-      const bool prior_here = (i == 0 || (i == N && pb.goal_on[b]));
+      // PriorFactor on x_0, v_0, x_N, v_N; the one on x_N can be switched off (a goal factor stands in)
+      const bool prior_here = (i == 0 || (i == N && pb.goal_on[b] && (ar || !P.end_conf_prior_off)));
       const double zz = z[rho];
       double z0 = 0.0, z1 = 0.0, z2 = 0.0;
       if (lie) { z0 = z[0]; z1 = z[1]; z2 = z[2]; }

@@ -62,7 +62,7 @@ int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, do
 
 // --------------------------------------------------------------------------- sphere centres
 template <int KIND, int AD, int AD2>
-__global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
+__global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf, int ld,
                                  double* __restrict__ centers, double* __restrict__ J) {
   using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF;
@@ -72,7 +72,7 @@ __global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const d
   if (m >= M) return;
   double q[D];
 #pragma unroll
-  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * D + k];
+  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * ld + k];   // ld: D, or 2 D for the states of a trajectory
   const int S = R.nr_spheres;
   K::for_each_sphere(R, q, [&](int s, const double (&p)[3], const double (&Jc)[D][3], int) {
     const int so = R.sph_orig[s];
@@ -90,7 +90,7 @@ __global__ void k_sphere_centers(const RobotDev* __restrict__ Rg, int M, const d
 // ForwardKinematics::forwardKinematics(jp, none, jpx, none, J_jpx_jp): poses [L][16], J [L][6][D]
 // in GTSAM Pose3 tangent order [omega; v] (body frame)  kinematics/Arm.cpp:105-115.
 template <int KIND, int AD, int AD2>
-__global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf,
+__global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __restrict__ conf, int ld,
                      double* __restrict__ poses, double* __restrict__ Jp) {
   using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF, L = K::NLINKS;
@@ -100,7 +100,7 @@ __global__ void k_fk(const RobotDev* __restrict__ Rg, int M, const double* __res
   if (m >= M) return;
   double q[D];
 #pragma unroll
-  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * D + k];
+  for (int k = 0; k < D; k++) q[k] = conf[(size_t)m * ld + k];
   double* P = poses + (size_t)m * L * 16;
   double* Jm = Jp ? Jp + (size_t)m * L * 6 * D : nullptr;
   auto put_pose = [&](int l, const Frame& F) {
@@ -675,15 +675,17 @@ __global__ void k_joint_limit(int D, const double* __restrict__ down, const doub
 #define G2_GRID(M) dim3(((M) + 63) / 64), dim3(64), 0, st
 
 int launch_sphere_centers(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* c,
-                          double* J, hipStream_t st) {
-  G2_DISPATCH_ROBOT_H(h, (k_sphere_centers<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, c, J)));
+                          double* J, hipStream_t st, int ld) {
+  if (ld <= 0) ld = h.dof;
+  G2_DISPATCH_ROBOT_H(h, (k_sphere_centers<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, ld, c, J)));
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
 
 int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* poses, double* J,
-              hipStream_t st) {
-  G2_DISPATCH_ROBOT_H(h, (k_fk<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, poses, J)));
+              hipStream_t st, int ld) {
+  if (ld <= 0) ld = h.dof;
+  G2_DISPATCH_ROBOT_H(h, (k_fk<KIND_, AD_, AD2_><<<G2_GRID(M)>>>(R, M, conf, ld, poses, J)));
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

@@ -11,10 +11,11 @@ int launch_sdf_from_occupancy(int nx, int ny, int nz, const double* occ, double 
 int launch_sdf_pack(const SdfDev& s, double* cells, hipStream_t st);
 int launch_sdf_query(const SdfDev& s, int M, const double* pts, double* dist, double* grad, int* inr,
                      hipStream_t st);
+// ld: leading dimension of conf (0 = dof; 2 dof reads the configurations out of trajectory states)
 int launch_sphere_centers(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* c,
-                          double* J, hipStream_t st);
+                          double* J, hipStream_t st, int ld = 0);
 int launch_fk(const RobotDev& h, const RobotDev* R, int M, const double* conf, double* poses, double* J,
-              hipStream_t st);
+              hipStream_t st, int ld = 0);
 int launch_obstacle(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, int M,
                     const double* conf, double* err, double* H1, hipStream_t st);
 int launch_obstacle_gp(const RobotDev& h, const RobotDev* R, const SdfDev& s, double eps, const GpCoef& gc,

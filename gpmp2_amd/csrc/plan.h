@@ -16,6 +16,7 @@ struct PlanParams {
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
+  int end_conf_prior_off;              // 1: no PriorFactor on x_N (a goal / workspace factor stands in)
   int wide;                            // 2 dof > 15: dense block path (k_export_normal_eq + k_solve_dense)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
@@ -35,6 +36,30 @@ struct PlanParams {
   // GP prior constant Hessian blocks (n x n row-major, ld = n): KA = Phi^T W Phi, KB = W,
   // KO = -Phi^T W (block (i, i+1))
   double KA[4 * MAXD * MAXD], KB[4 * MAXD * MAXD], KO[4 * MAXD * MAXD];
+};
+
+// Extra factors a plan carries as data (gpmp2mi_graph_opts): workspace priors / goal factor and self collision on
+// ranges of support states.  They are unary in x_i, so their J^T J / sigma^2, J^T r / sigma^2, r^T r / sigma^2 are
+// added to the record of the state's unary evaluation point after k_linearize (launch_extra_factors); the solver
+// kernels never see them separately.
+struct PlanExtras {
+  int n_ws, n_sc, sc_first, sc_last;
+  int ws_mode[GPMP2MI_MAX_WORKSPACE_FACTORS], ws_link[GPMP2MI_MAX_WORKSPACE_FACTORS];
+  int ws_first[GPMP2MI_MAX_WORKSPACE_FACTORS], ws_last[GPMP2MI_MAX_WORKSPACE_FACTORS];
+  double ws_w[GPMP2MI_MAX_WORKSPACE_FACTORS];                       // 1 / sigma^2
+  double sc_w[GPMP2MI_MAX_SELF_COLLISION_PAIRS];                    // 1 / sigma^2
+  // device workspace, M = B (N + 1) states
+  double* des;       // [n_ws][16]
+  double* sc_data;   // [n_sc][4]
+  double* radius;    // [S] caller's sphere order
+  double* poses;     // [M][L][16]
+  double* Jp;        // [M][L][6][D]
+  double* ws_err;    // [n_ws][M][6]
+  double* ws_H;      // [n_ws][M][6][D]
+  double* cen;       // [M][S][3]
+  double* Jc;        // [M][S][3][D]
+  double* sc_err;    // [M][n_sc]
+  double* sc_H;      // [M][n_sc][D]
 };
 
 // Per-plan device buffers.
@@ -107,6 +132,8 @@ __host__ __device__ inline double* gpu_of(const PlanBuffers& pb, int which_b, in
 int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
                      const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                      const int* active, hipStream_t st);
+int launch_extra_accumulate(const PlanParams& hp, const PlanBuffers& pb, const PlanExtras& ex, int L, int S, int bufsel,
+                            const int* active, hipStream_t st);
 int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st);

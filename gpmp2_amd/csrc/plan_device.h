@@ -20,7 +20,7 @@ __device__ __forceinline__ double misc_error_partial(const PlanParams& P, const 
     const int i = idx / n, rho = idx - i * n;
     const int a = rho >= D, k = rho - a * D;
     const double z = tr[idx];
-    if (i == 0 || (i == N && pb.goal_on[b])) {
+    if (i == 0 || (i == N && pb.goal_on[b] && (a || !P.end_conf_prior_off))) {
       const double* tg = (i == 0) ? (a ? pb.start_vel : pb.start_conf) : (a ? pb.end_vel : pb.end_conf);
       tg += (size_t)b * D;
       double d = z - tg[k];

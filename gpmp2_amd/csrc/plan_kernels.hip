@@ -236,6 +236,55 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   return GPMP2MI_OK;
 }
 
+// =============================================================================== extra factors
+// One lane per (trajectory, support state): adds the whitened normal-equation terms of the workspace priors /
+// goal factor / self-collision rows of that state to the record of its unary evaluation point
+// (p = i (I + 1)): G += H^T H / sigma^2, g += H^T r / sigma^2, e += r^T r / sigma^2.  The residuals and Jacobians come
+// from the factor kernels (k_fk + k_workspace_prior, k_sphere_centers + k_self_collision) run on the states.
+__global__ __launch_bounds__(64) void k_extra_accumulate(const PlanParams* __restrict__ pp, PlanBuffers pb, PlanExtras ex,
+                                                          int bufsel, const int* __restrict__ active) {
+  const PlanParams& P = *pp;
+  const int N = P.N, D = P.D, M = P.B * (N + 1);
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = m / (N + 1), i = m - b * (N + 1);
+  if (active && !active[b]) return;
+  double* rec = rec_of(pb, pb.which[b], bufsel) + ((size_t)b * P.Ppad + (size_t)i * (P.I + 1)) * P.RECS;
+  auto add_rows = [&](const double* err, const double* H, int rows, const double* w, double wu) {
+    // rows x D Jacobian H (row-major), residual err; weight w[r] per row (or the uniform wu when w == nullptr)
+    double e = 0.0;
+    for (int r = 0; r < rows; r++) e += (w ? w[r] : wu) * err[r] * err[r];
+    rec[P.NG + D] += e;
+    for (int k = 0; k < D; k++) {
+      double g = 0.0;
+      for (int r = 0; r < rows; r++) g += (w ? w[r] : wu) * H[r * D + k] * err[r];
+      rec[P.NG + k] += g;
+      for (int k2 = k; k2 < D; k2++) {
+        double a = 0.0;
+        for (int r = 0; r < rows; r++) a += (w ? w[r] : wu) * H[r * D + k] * H[r * D + k2];
+        rec[k * D - (k * (k - 1)) / 2 + (k2 - k)] += a;
+      }
+    }
+  };
+  for (int f = 0; f < ex.n_ws; f++) {
+    if (i < ex.ws_first[f] || i > ex.ws_last[f]) continue;
+    const int rows = ex.ws_mode[f] == GPMP2MI_WORKSPACE_POSE ? 6 : 3;
+    // (k_workspace_prior packs `rows` per state; every factor owns a slice sized for 6)
+    add_rows(ex.ws_err + (size_t)f * M * 6 + (size_t)m * rows, ex.ws_H + ((size_t)f * M * 6 + (size_t)m * rows) * D, rows,
+             nullptr, ex.ws_w[f]);
+  }
+  if (ex.n_sc > 0 && i >= ex.sc_first && i <= ex.sc_last)
+    add_rows(ex.sc_err + (size_t)m * ex.n_sc, ex.sc_H + (size_t)m * ex.n_sc * D, ex.n_sc, ex.sc_w, 0.0);
+}
+
+int launch_extra_accumulate(const PlanParams& hp, const PlanBuffers& pb, const PlanExtras& ex, int L, int S, int bufsel,
+                            const int* active, hipStream_t st) {
+  const int M = hp.B * (hp.N + 1);
+  k_extra_accumulate<<<dim3((M + 63) / 64), dim3(64), 0, st>>>(pb.params, pb, ex, bufsel, active);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 __global__ __launch_bounds__(64) void k_error_reduce(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                       const double* __restrict__ traj, int bufsel,
                                                       double* __restrict__ err) {

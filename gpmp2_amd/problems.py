@@ -219,3 +219,76 @@ def mobile_arm_config5():
     z = np.zeros((1, 5))
     return Problem("mobile_arm_config5", model, [d.origin_x, d.origin_y], d.cell_size, field, s, start[None], z.copy(),
                    end[None], z.copy(), init)
+
+
+def arm3_goal_reach():
+    """matlab/Arm3GoalReachExample.m: 3-link planar arm, TwoObstaclesDataset, N = 10, 4 interpolated checks,
+    hand-built graph: start priors, GoalFactorArm on x_N INSTEAD of the end-conf prior (:105-109), end-velocity
+    prior, GP priors, planar obstacle factors for i > 0; Dogleg with GTSAM defaults (:151-158)."""
+    model = robots.generateArm("SimpleThreeLinksArm")
+    d = datasets.generate2Ddataset("TwoObstaclesDataset")
+    field = datasets.signedDistanceField2D(d.map, d.cell_size)
+    N = 10
+    s = TrajOptimizerSetting(3)
+    s.set_total_step(N)
+    s.set_total_time(5.0)
+    s.set_obs_check_inter(4)
+    s.set_cost_sigma(0.1)
+    s.set_epsilon(0.1)
+    s.set_conf_prior_model(0.0001)
+    s.set_vel_prior_model(0.0001)
+    s.set_Qc_model(np.eye(3))
+    s.setDogleg()
+    s.dogleg_delta_initial = 1.0           # gtsam DoglegParams defaults (the script calls GTSAM directly)
+    s.set_max_iter(100)
+    s.set_rel_thresh(1e-5)
+    s.setOptimizationNoIncrase(False)
+    s.obs_skip_first_state = True
+    s.end_conf_prior_off = True
+    s.add_goal_factor_arm(link=2, dest_point=(0.0, 1.1, 0.0), sigma=0.0001)
+    start = np.zeros(3)
+    init = np.zeros((1, N + 1, 6))        # end_conf_init = 0, avg_vel = 0 (:70-75)
+    z = np.zeros((1, 3))
+    return Problem("arm3_goal_reach", model, [d.origin_x, d.origin_y], d.cell_size, field, s, start[None], z.copy(),
+                   np.zeros((1, 3)), z.copy(), init)
+
+
+def wam_workspace_constraints(fk_pose, sdf="synth200", B=1):
+    """matlab/WAMWorkspaceConstraintsExample.m: WAM, N = 10, 5 interpolated checks, Qc = 0.1 I, obstacle sigma 0.005,
+    epsilon 0.15; hand-built graph: start priors, GaussianPriorWorkspaceOrientationArm (sigma 1e-2, the start pose's
+    end-effector orientation) on every interior state, GaussianPriorWorkspacePoseArm (sigma 1e-4, the end
+    configuration's end-effector pose) on x_N instead of the end-conf prior, end-velocity prior; LM, lambda0 = 1000,
+    GTSAM defaults (:131-140).  fk_pose(model, conf) -> 4x4 pose of the last link (the caller's FK: the engine's on
+    the GPU, the oracle's in CPU tests).  The script's 300^3 WAMDeskDataset field is replaced by `sdf`."""
+    model = robots.generateArm("WAMArm")
+    origin, cell, data = synth200_sdf() if sdf == "synth200" else small3d_sdf(int(sdf))
+    N = 10
+    start = np.array([-0.0, 0.94, 0, 1.6, 0, -0.919, 1.55])
+    end = np.array([-0.8, -1.70, 1.64, 1.29, 1.1, -0.106, 2.2])
+    s = TrajOptimizerSetting(7)
+    s.set_total_step(N)
+    s.set_total_time(2.0)
+    s.set_obs_check_inter(5)
+    s.set_cost_sigma(0.005)
+    s.set_epsilon(0.15)
+    s.set_conf_prior_model(1e-4)
+    s.set_vel_prior_model(1e-4)
+    s.set_Qc_model(0.1 * np.eye(7))
+    s.setLM()
+    s.lm_lambda_initial = 1000.0
+    s.set_max_iter(100)
+    s.set_rel_thresh(1e-5)
+    s.setOptimizationNoIncrase(False)
+    s.obs_skip_first_state = True
+    s.end_conf_prior_off = True
+    traj_orien = np.eye(4)
+    traj_orien[:3, :3] = fk_pose(model, start)[:3, :3]
+    s.add_workspace_prior(1, 6, traj_orien, 1e-2, 1, N - 1)
+    s.add_workspace_prior(2, 6, fk_pose(model, end), 1e-4, N)
+    base = initArmTrajStraightLine(start, start, N)      # the script starts from the start configuration everywhere
+    init = np.repeat(base[None], B, axis=0)
+    for b in range(1, B):
+        init[b, :, :7] += 0.05 * np.random.default_rng(99 + b).normal(size=(N + 1, 7)) * np.sin(math.pi * np.arange(N + 1) / N)[:, None]
+    z = np.zeros((B, 7))
+    return Problem("wam_workspace_constraints", model, origin, cell, data, s, np.repeat(start[None], B, 0), z.copy(),
+                   np.repeat(end[None], B, 0), z.copy(), init)

@@ -47,6 +47,27 @@ class TrajOptimizerSetting:
         self.abs_error_tol = 1e-5
         self.error_tol = 0.0
         self.fixed_iterations = 0
+        # extra factors of hand-built graphs, carried by the plan as data (include/gpmp2mi.h gpmp2mi_graph_opts)
+        self.end_conf_prior_off = False      # no PriorFactor on x_N (a goal / workspace factor replaces it)
+        self.workspace_factors = []          # dicts(mode, link, first_state, last_state, sigma, des_pose 4x4)
+        self.self_collision = None           # [n][4] = sphere A, sphere B, epsilon, sigma
+        self.self_collision_states = None    # (first, last) support states, default all
+
+    # extra factors (names follow the reference's factor classes)
+    def add_goal_factor_arm(self, link, dest_point, sigma, state=None):
+        """GoalFactorArm (kinematics/GoalFactorArm.h:58-77) on `state` (default: the last), replacing nothing by
+        itself: set end_conf_prior_off to drop the prior on x_N as matlab/Arm3GoalReachExample.m:107 does"""
+        des = np.eye(4)
+        des[:3, 3] = np.asarray(dest_point, dtype=np.float64)
+        st = self.total_step if state is None else int(state)
+        self.workspace_factors.append(dict(mode=0, link=int(link), first_state=st, last_state=st, sigma=float(sigma),
+                                           des_pose=des))
+
+    def add_workspace_prior(self, mode, link, des_pose, sigma, first_state, last_state=None):
+        """GaussianPriorWorkspace{Position (0), Orientation (1), Pose (2)}<Arm> on states first_state..last_state"""
+        self.workspace_factors.append(dict(mode=int(mode), link=int(link), first_state=int(first_state),
+                                           last_state=int(first_state if last_state is None else last_state),
+                                           sigma=float(sigma), des_pose=np.asarray(des_pose, dtype=np.float64).reshape(4, 4)))
 
     # traj settings
     def set_total_step(self, step): self.total_step = int(step)

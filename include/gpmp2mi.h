@@ -182,6 +182,24 @@ void gpmp2mi_settings_default(gpmp2mi_settings* s, int dof);
 /* Knobs that are NOT in TrajOptimizerSetting but differ between BatchTrajOptimize and the
  * hand-built graphs of the example scripts or are hard-coded GTSAM
  * parameters in gpmp2::optimize (planner/BatchTrajOptimizer.cpp:219-234). */
+#define GPMP2MI_WORKSPACE_POSITION 0
+#define GPMP2MI_WORKSPACE_ORIENTATION 1
+#define GPMP2MI_WORKSPACE_POSE 2
+#define GPMP2MI_MAX_WORKSPACE_FACTORS 4
+#define GPMP2MI_MAX_SELF_COLLISION_PAIRS 16
+/* A workspace factor carried by a plan: GaussianPriorWorkspace{Position,Orientation,Pose}<Arm>
+ * (kinematics/GaussianPriorWorkspacePosition.h:52-67, ...Orientation.h:52-69, ...Pose.h:53-70) or GoalFactorArm
+ * (kinematics/GoalFactorArm.h:58-77 = POSITION on the last link) on the support states first_state..last_state,
+ * isotropic noise `sigma`, as the hand-built graphs of matlab/Arm3GoalReachExample.m:95-110 and
+ * matlab/WAMWorkspaceConstraintsExample.m:85-105 add them. */
+typedef struct gpmp2mi_workspace_factor {
+  int mode;                     /* GPMP2MI_WORKSPACE_POSITION / _ORIENTATION / _POSE */
+  int link;                     /* link index of the FK model (GoalFactorArm: arm dof - 1) */
+  int first_state, last_state;  /* inclusive range of support states */
+  double sigma;
+  double des_pose[16];          /* row-major 4x4 (POSITION uses the translation, ORIENTATION the rotation) */
+} gpmp2mi_workspace_factor;
+
 typedef struct gpmp2mi_graph_opts {
   int obs_skip_first_state;      /* 1: unary obstacle factors only for i>0
                                     (matlab/WAMFactorGraphExample.m:126-138); default 0 */
@@ -197,6 +215,16 @@ typedef struct gpmp2mi_graph_opts {
   double error_tol;              /* default 0 */
   int fixed_iterations;          /* >0: run exactly this many iterations, no convergence test
                                     (receding-horizon budget, BASELINE config 4); default 0 */
+  /* ---- extra factors of hand-built graphs, as data (gpmp2::optimize takes any NonlinearFactorGraph,
+   * planner/BatchTrajOptimizer.h:206-208); all default to none */
+  int end_conf_prior_off;        /* 1: no PriorFactor on x_N (a goal / workspace factor takes its place,
+                                    matlab/Arm3GoalReachExample.m:107); the prior on v_N stays */
+  int n_workspace;               /* <= GPMP2MI_MAX_WORKSPACE_FACTORS */
+  gpmp2mi_workspace_factor workspace[GPMP2MI_MAX_WORKSPACE_FACTORS];
+  int n_self_collision;          /* SelfCollision<Arm> (obstacle/SelfCollision.h:66-128) on the support states
+                                    self_collision_first..last; <= GPMP2MI_MAX_SELF_COLLISION_PAIRS rows */
+  int self_collision_first, self_collision_last;
+  double self_collision[GPMP2MI_MAX_SELF_COLLISION_PAIRS][4];  /* sphere A, sphere B, epsilon, sigma */
 } gpmp2mi_graph_opts;
 void gpmp2mi_graph_opts_default(gpmp2mi_graph_opts* o);
 
@@ -350,9 +378,6 @@ int gpmp2mi_interpolate_traj_dev(int dof, int lie, double delta_t, int inter_ste
  * translation, orientation mode its rotation).  -> err [M][3|3|6] (pose: [omega; u] of
  * Pose3::Logmap(des^-1 * pose)), H [M][rows][D] (may be NULL).  Rot3 / Pose3 log maps follow
  * GTSAM 4.0 (upstream; pinned by the reference's known answers). */
-#define GPMP2MI_WORKSPACE_POSITION 0
-#define GPMP2MI_WORKSPACE_ORIENTATION 1
-#define GPMP2MI_WORKSPACE_POSE 2
 int gpmp2mi_workspace_prior_factor(const gpmp2mi_robot* r, int mode, int joint,
                                    const double des_pose[16], int M, const double* conf,
                                    double* err, double* H);

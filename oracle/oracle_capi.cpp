@@ -73,6 +73,21 @@ static void fill_settings(const gpmp2mi_settings* s, const gpmp2mi_graph_opts* o
     S.abs_error_tol = o->abs_error_tol;
     S.error_tol = o->error_tol;
     S.fixed_iterations = o->fixed_iterations;
+    S.end_conf_prior_off = o->end_conf_prior_off != 0;
+    for (int k = 0; k < o->n_workspace; k++) {
+      Settings::WorkspaceFactor w;
+      w.mode = o->workspace[k].mode;
+      w.link = o->workspace[k].link;
+      w.first_state = o->workspace[k].first_state;
+      w.last_state = o->workspace[k].last_state;
+      w.sigma = o->workspace[k].sigma;
+      for (int t = 0; t < 16; t++) w.des[t] = o->workspace[k].des_pose[t];
+      S.workspace.push_back(w);
+    }
+    for (int k = 0; k < o->n_self_collision; k++)
+      for (int t = 0; t < 4; t++) S.self_collision.push_back(o->self_collision[k][t]);
+    S.self_collision_first = o->self_collision_first;
+    S.self_collision_last = o->self_collision_last;
   }
 }
 

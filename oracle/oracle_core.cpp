@@ -1146,10 +1146,13 @@ double Problem::linearize(const double* traj, std::vector<LinFactor>* F) const {
     if (i == 0 || (i == N && set.goal_on)) {
       const double* pc = (i == 0) ? start_conf.data() : end_conf.data();
       const double* pv = (i == 0) ? start_vel.data() : end_vel.data();
+      const bool conf_prior = !(i == N && set.end_conf_prior_off);  // a goal factor may stand in for it
       LinFactor f;
       f.s0 = i; f.ns = 1; f.m = d; f.r.assign(d, 0.0);
       if (F) f.A.assign((size_t)d * n, 0.0);
-      if (lie) {
+      if (!conf_prior) {
+        // no factor (rows stay zero: contributes nothing to the error or the normal equations)
+      } else if (lie) {
         // gtsam 4.0.x PriorFactor<T>::evaluateError: H = Identity, error = -Local(x, prior)
         // (ProductDynamicLieGroup::localCoordinates throws when Jacobians are requested,
         // geometry/ProductDynamicLieGroup.h:92-101, so only this PriorFactor form can work with
@@ -1201,6 +1204,38 @@ double Problem::linearize(const double* traj, std::vector<LinFactor>* F) const {
         }
         push(std::move(f));
       }
+    }
+    // workspace priors / goal factor on this state (isotropic noise)
+    for (const auto& w : set.workspace) {
+      if (i < w.first_state || i > w.last_state) continue;
+      const int rows = (w.mode == WS_POSE) ? 6 : 3;
+      std::vector<double> e(rows), H((size_t)rows * d);
+      workspace_prior_factor(*robot, w.mode, w.link, w.des, x, e.data(), H.data());
+      LinFactor f;
+      f.s0 = i; f.ns = 1; f.m = rows; f.r.assign(rows, 0.0);
+      if (F) f.A.assign((size_t)rows * n, 0.0);
+      for (int a = 0; a < rows; a++) {
+        f.r[a] = e[a] / w.sigma;
+        if (F)
+          for (int k = 0; k < d; k++) f.A[(size_t)a * n + k] = H[(size_t)a * d + k] / w.sigma;
+      }
+      push(std::move(f));
+    }
+    // self collision (Diagonal::Sigmas(data.col(3)))
+    if (!set.self_collision.empty() && i >= set.self_collision_first && i <= set.self_collision_last) {
+      const int np = (int)set.self_collision.size() / 4;
+      std::vector<double> e(np), H((size_t)np * d);
+      self_collision_factor(*robot, np, set.self_collision.data(), x, e.data(), H.data());
+      LinFactor f;
+      f.s0 = i; f.ns = 1; f.m = np; f.r.assign(np, 0.0);
+      if (F) f.A.assign((size_t)np * n, 0.0);
+      for (int a = 0; a < np; a++) {
+        const double sg = set.self_collision[(size_t)a * 4 + 3];
+        f.r[a] = e[a] / sg;
+        if (F)
+          for (int k = 0; k < d; k++) f.A[(size_t)a * n + k] = H[(size_t)a * d + k] / sg;
+      }
+      push(std::move(f));
     }
     // joint / velocity limits  (BatchTrajOptimizer-inl.h:50-59)
     if (set.flag_pos_limit) {

@@ -165,6 +165,17 @@ struct Settings {
          lm_lambda_lower = 0, lm_min_model_fidelity = 1e-3;
   double dogleg_delta_initial = 0.2, abs_error_tol = 1e-5, error_tol = 0;
   int fixed_iterations = 0;
+  // extra factors of hand-built graphs (matlab/Arm3GoalReachExample.m:95-110,
+  // matlab/WAMWorkspaceConstraintsExample.m:85-105, obstacle/SelfCollision.h:66-128)
+  bool end_conf_prior_off = false;
+  struct WorkspaceFactor {
+    int mode = 0, link = 0, first_state = 0, last_state = 0;
+    double sigma = 1.0;
+    double des[16] = {0};
+  };
+  std::vector<WorkspaceFactor> workspace;
+  std::vector<double> self_collision;  // [n][4]
+  int self_collision_first = 0, self_collision_last = 0;
   // replanner state (planner/ISAM2TrajOptimizer-inl.h:118-195)
   bool goal_on = true;
   struct StatePrior {

@@ -171,3 +171,51 @@ def test_reference_small_graph_solves(oracle, golden):
         st, sc, sv, ec, ev, init = joint_limit_graph_problem(golden, conf)
         res = oracle.batch_optimize(r2, s, st, sc, sv, ec, ev, init)
         np.testing.assert_allclose(res["traj"][0, :, :2], [want, want], atol=1e-6)
+
+
+# ------------------------------------------------------------------ extra factors carried by a plan as data
+def _numeric_gradient(oracle, ro, so, p, traj, h=1e-6):
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    g = np.zeros_like(traj)
+    flat, gf = traj.reshape(-1), g.reshape(-1)
+    for k in range(flat.size):
+        keep = flat[k]
+        flat[k] = keep + h
+        ep = oracle.graph_error(ro, so, p.setting, *args, traj)[0]
+        flat[k] = keep - h
+        em = oracle.graph_error(ro, so, p.setting, *args, traj)[0]
+        flat[k] = keep
+        gf[k] = (ep - em) / (2 * h)
+    return g
+
+
+def test_goal_reach_graph_in_the_oracle(oracle):
+    """matlab/Arm3GoalReachExample.m through the oracle: the GoalFactorArm rows are in the gradient (numeric check of
+    d error / d x against J^T r) and the solve brings the end effector to the goal point with no end configuration"""
+    from gpmp2_amd import problems
+    p = problems.arm3_goal_reach()
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    traj = p.init + 0.05 * np.random.default_rng(8).normal(size=p.init.shape)
+    _, _, g, _ = oracle.linearize(ro, so, p.setting, *args, traj)
+    gn = _numeric_gradient(oracle, ro, so, p, traj.copy())
+    np.testing.assert_allclose(g, gn.reshape(g.shape), rtol=2e-5, atol=2e-5 * np.abs(gn).max())
+    res = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+    poses, _ = oracle.forward_kinematics(ro, res["traj"][0, -1, :3])
+    np.testing.assert_allclose(poses[0, 2, :3, 3], [0.0, 1.1, 0.0], atol=1e-3)
+    assert res["final_error"][0] < 0.1 * oracle.graph_error(ro, so, p.setting, *args, p.init)[0]
+
+
+def test_workspace_and_self_collision_rows_in_the_oracle(oracle):
+    """WAMWorkspaceConstraintsExample graph + SelfCollisionArm rows: gradient of the oracle's factor list against
+    numeric differentiation of its graph error"""
+    from gpmp2_amd import problems
+    fk = lambda model, q: oracle.forward_kinematics(oracle.robot(model), q)[0][0, 6]
+    p = problems.wam_workspace_constraints(fk, sdf="24", B=1)
+    p.setting.self_collision = np.array([[0, 9, 0.6, 0.05], [5, 12, 0.4, 0.05]])
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    traj = p.init + 0.1 * np.random.default_rng(9).normal(size=p.init.shape)
+    _, _, g, _ = oracle.linearize(ro, so, p.setting, *args, traj)
+    gn = _numeric_gradient(oracle, ro, so, p, traj.copy(), h=1e-7)
+    np.testing.assert_allclose(g, gn.reshape(g.shape), rtol=1e-4, atol=1e-4 * np.abs(gn).max())
