@@ -287,7 +287,7 @@ int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
   G2_CHECK(d && out, GPMP2MI_ERR_INVALID, "null argument");
   *out = nullptr;
   G2_CHECK(d->kind >= 0 && d->kind <= GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, GPMP2MI_ERR_INVALID, "unknown robot kind");
-  G2_CHECK(d->arm_dof >= 0 && d->arm_dof <= MAXJ, GPMP2MI_ERR_UNSUPPORTED, "arm dof > 8");
+  G2_CHECK(d->arm_dof >= 0 && d->arm_dof <= MAXJ, GPMP2MI_ERR_UNSUPPORTED, "more than 14 arm joints");
   G2_CHECK(d->nr_spheres >= 0 && d->nr_spheres <= MAXS, GPMP2MI_ERR_UNSUPPORTED, "too many body spheres");
   const bool mobile = d->kind >= GPMP2MI_ROBOT_POSE2_MOBILE_BASE;
   const bool lift = d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM || d->kind == GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS;
@@ -295,7 +295,7 @@ int gpmp2mi_robot_create(const gpmp2mi_robot_desc* d, gpmp2mi_robot** out) {
   const int base = mobile ? 3 : 0;
   const int dof = (d->kind == GPMP2MI_ROBOT_POINT) ? 2 : base + (lift ? 1 : 0) + d->arm_dof;
   G2_CHECK(d->dof == dof, GPMP2MI_ERR_INVALID, "dof does not match robot kind / arm_dof");
-  G2_CHECK(dof <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "total dof > 11");
+  G2_CHECK(dof <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "total dof > 18");
   if (d->kind == GPMP2MI_ROBOT_ARM || d->kind >= GPMP2MI_ROBOT_POSE2_MOBILE_ARM)
     G2_CHECK(d->arm_dof > 0 && d->a && d->alpha && d->d, GPMP2MI_ERR_INVALID, "missing DH parameters");
   if (two) G2_CHECK(d->arm2_dof > 0 && d->arm2_dof < d->arm_dof, GPMP2MI_ERR_INVALID, "arm2_dof must split arm_dof into two arms");
@@ -837,14 +837,15 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->dof == D, GPMP2MI_ERR_INVALID, "[TrajOptimizerSetting] dof does not match the robot");
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
-  G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 11");
-  const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: dense block path
+  G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 18");
+  const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: 2x2-tile cyclic reduction (dof <= 11)
+  const bool dense_only = D > 11; // 12 <= dof <= 18 (PR2): dense normal equations + dense block Cholesky
   {
     // the assembler stages an interval with at most NLD2 16-B loads per lane (assembler.h: 6, 9 on the wide path)
     const int nd = D * (D + 1) / 2 + D + 1 + ((robot->h.base_dof == 3 && s->obs_check_inter > 0) ? 36 : 0);
     const int gpr = 2 * D + 1 + (robot->h.base_dof == 3 ? 18 : 0);
     const int nds = (nd + 1) & ~1, gps = (gpr + 1) & ~1;
-    G2_CHECK((s->obs_check_inter + 1) * nds + gps + 24 * s->obs_check_inter <= 2 * 64 * (wide ? 9 : 6), GPMP2MI_ERR_UNSUPPORTED,
+    G2_CHECK((s->obs_check_inter + 1) * nds + gps + 24 * s->obs_check_inter <= 2 * 64 * (dense_only ? 14 : wide ? 9 : 6), GPMP2MI_ERR_UNSUPPORTED,
              "obs_check_inter too large for the staged assembly");
   }
   G2_CHECK(s->opt_type >= GPMP2MI_OPT_GAUSS_NEWTON && s->opt_type <= GPMP2MI_OPT_DOGLEG, GPMP2MI_ERR_INVALID,
@@ -1008,7 +1009,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     const char* e = getenv("GPMP2MI_GENERIC_GN");
     p->generic_gn = e && e[0] == '1';
     const char* wd = getenv("GPMP2MI_WIDE_DENSE");
-    p->wide_dense = wd && wd[0] == '1';
+    p->wide_dense = (wd && wd[0] == '1') || dense_only;
     const int cap = std::max(P.fixed_iters, P.max_iter);   // plan_update may run any iterations <= max_iter
     // passes: GN one per iteration (+1); LM up to ~5 lambda retries per iterate; Dogleg up to ~16 halvings
     const int mult = P.opt_type == GPMP2MI_OPT_LM ? 6 : P.opt_type == GPMP2MI_OPT_DOGLEG ? 18 : 1;

@@ -80,7 +80,7 @@ struct Assembler {
   // LDS store so the wavefront pays one memory latency; NLD2 bounds the per-lane load count (checked on
   // the host).  The weight table of the sub-steps rides along into the slot (LDS reads later instead of scalar
   // loads and per-entry products inside the accumulation loops).
-  static constexpr int NLD2 = (D <= 7) ? 6 : 9;
+  static constexpr int NLD2 = (D <= 7) ? 6 : (D <= 11) ? 9 : 14;
   // count = 1 stages interval iv only (kernels whose wavefronts share their slots)
   __device__ __forceinline__ void stage2(int iv, const Slot& s0, const Slot& s1, int count = 2) const {
     const int I = P.I, RECS = P.RECS, GPS = P.GPS;

@@ -9,9 +9,9 @@
 
 namespace g2 {
 
-constexpr int MAXJ = 8;                     // DH joints a kernel is instantiated for
+constexpr int MAXJ = 14;                    // DH joints a kernel is instantiated for (two 7-joint arms)
 constexpr int MAXS = GPMP2MI_MAX_SPHERES;   // sphere model staged on chip
-constexpr int MAXD = 11;                    // max total dof (3 base + 8 arm)
+constexpr int MAXD = GPMP2MI_MAX_DOF;       // max total dof (3 base + 1 lift + 7 + 7 arm joints: the PR2 model)
 constexpr int REC_G_MAX = MAXD * (MAXD + 1) / 2;
 
 // ---------------------------------------------------------------- error plumbing
@@ -53,7 +53,7 @@ struct RobotDev {
   int arm2_dof, reverse_linact;
   int sph_link[MAXS];        // ascending
   int sph_orig[MAXS];        // index in the caller's BodySphereVector
-  int link_first[MAXJ + 2];  // first sorted sphere of each link, [nr_links] = nr_spheres
+  int link_first[MAXJ + 4];  // first sorted sphere of each link (vehicle base + torso + MAXJ arm links), [nr_links] = nr_spheres
   double sph_r[MAXS];
   double sph_c[MAXS * 3];
 };

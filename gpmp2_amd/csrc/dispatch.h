@@ -47,6 +47,7 @@
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_ARM, 7, 0, kind, ad, ad2, STMT)       \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 2, 2, kind, ad, ad2, STMT)     \
     G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 3, 3, kind, ad, ad2, STMT)     \
+    G2_CASE2_(GPMP2MI_ROBOT_POSE2_MOBILE_VETLIN_2ARMS, 7, 7, kind, ad, ad2, STMT)     \
     if (!done_) {                                                                     \
       g2::set_error("robot kind / dof combination is not instantiated");              \
       return GPMP2MI_ERR_UNSUPPORTED;                                                 \

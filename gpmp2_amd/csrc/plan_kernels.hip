@@ -537,9 +537,9 @@ __global__ __launch_bounds__(64) void k_export_normal_eq(const PlanParams* __res
   const typename Asm::Slot slot0 = as.make_slot(asm_smem, 0), slot1 = as.make_slot(asm_smem, 1);
   as.stage2(i, slot0, slot1);
   __syncthreads();
-  // blocks wider than one tile (2 dof > 15) are walked as 2x2 tiles; the right-hand side rides in the last
-  // column of the tile grid
-  constexpr int T = (n <= 15) ? 1 : 2, RC = 16 * T - 1;
+  // blocks wider than one tile (2 dof > 15) are walked as 2x2 (3x3 for 2 dof > 31) tiles; the right-hand side
+  // rides in the last column of the tile grid
+  constexpr int T = (n <= 15) ? 1 : (n <= 31) ? 2 : 3, RC = 16 * T - 1;
   const double* zi = traj + ((size_t)b * (N + 1) + i) * n;
   for (int ti = 0; ti < T; ti++)
     for (int tj = 0; tj < T; tj++) {
@@ -571,10 +571,10 @@ int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const d
     else k_export_normal_eq<DD, false><<<grid, block, shmem, st>>>(pb.params, pb, traj, bufsel, Hd, Ho, g, active);       \
     break;
     G2_EXP_CASE(1) G2_EXP_CASE(2) G2_EXP_CASE(3) G2_EXP_CASE(4) G2_EXP_CASE(5) G2_EXP_CASE(6) G2_EXP_CASE(7)
-    G2_EXP_CASE(8) G2_EXP_CASE(9) G2_EXP_CASE(10) G2_EXP_CASE(11)
+    G2_EXP_CASE(8) G2_EXP_CASE(9) G2_EXP_CASE(10) G2_EXP_CASE(11) G2_EXP_CASE(17) G2_EXP_CASE(18)
 #undef G2_EXP_CASE
     default:
-      set_error("dof > 11");
+      set_error("normal equations are instantiated for dof <= 11 and 17, 18");
       return GPMP2MI_ERR_UNSUPPORTED;
   }
   G2_HIP(hipGetLastError());

@@ -270,6 +270,8 @@ def generateArm(arm_str: str, base_pose=None) -> RobotModel:
 
 def generateMobileArm(name: str, base_T_arm=None) -> RobotModel:
     """matlab/+gpmp2/generateMobileArm.m:20-51."""
+    if name == "PR2":
+        return _generate_pr2()
     if name != "SimpleTwoLinksArm":
         raise ValueError("No such mobile arm exist")
     arm = Arm(2, [0.3, 0.3], [0, 0], [0, 0])
@@ -278,6 +280,41 @@ def generateMobileArm(name: str, base_T_arm=None) -> RobotModel:
             [1, -0.3, 0, 0, 0.05], [1, -0.2, 0, 0, 0.05], [1, -0.1, 0, 0, 0.05],
             [2, -0.3, 0, 0, 0.05], [2, -0.2, 0, 0, 0.05], [2, -0.1, 0, 0, 0.05], [2, 0.0, 0, 0, 0.05]]
     return Pose2MobileArmModel(marm, _spheres(rows))
+
+
+def _generate_pr2() -> RobotModel:
+    """matlab/+gpmp2/generateMobileArm.m:244-349 'PR2': SE(2) base + vertical lift torso + two 7-joint arms (dof 18),
+    65 body spheres (data table restated: link, x, y, z, radius)."""
+    hp = 1.5708
+    arm = Arm(7, [0.1, 0, 0, 0, 0, 0, 0], [-hp, hp, -hp, hp, -hp, hp, 0], [0, 0, 0.4, 0, 0.321, 0, 0], None,
+              [0, hp, 0, 0, 0, 0, 0])
+    marm = Pose2MobileVetLin2Arms(arm, arm, pose3(t=(-0.05, 0.0, 0.790675)), pose3(t=(0.0, 0.188, 0.0)),
+                                  pose3(t=(0.0, -0.188, 0.0)), False)
+    base = [[0, 0.0, 0.0, 0.13, 0.17], [0, 0.23, 0.0, 0.13, 0.17], [0, -0.23, 0.0, 0.13, 0.17], [0, 0.23, 0.23, 0.13, 0.17],
+            [0, 0.0, 0.23, 0.13, 0.17], [0, 0.0, -0.23, 0.13, 0.17], [0, 0.23, -0.23, 0.13, 0.17],
+            [0, -0.23, -0.23, 0.13, 0.17], [0, -0.23, 0.23, 0.13, 0.17],
+            [0, -0.27, 0.0, 0.38, 0.08], [0, -0.27, 0.16, 0.38, 0.08], [0, -0.27, -0.16, 0.38, 0.08],
+            [0, -0.27, 0.0, 0.54, 0.08], [0, -0.27, 0.14, 0.54, 0.08], [0, -0.27, -0.14, 0.54, 0.08]]
+    torso = [[1, -0.11, 0.0, 0.1, 0.25], [1, -0.09, -0.12, -0.34, 0.2], [1, -0.09, 0.12, -0.34, 0.2],
+             [1, -0.02, 0.0, 0.37, 0.17]]
+
+    def one_arm(l0):   # l0 = link id of the arm's first link (2: left, 9: right)
+        return [[l0, -0.01, 0.0, 0.0, 0.18],
+                [l0 + 2, 0.015, 0.22, -0.0, 0.11], [l0 + 2, 0.035, 0.14, -0.0, 0.08], [l0 + 2, 0.035, 0.0725, -0.0, 0.08],
+                [l0 + 2, 0.0, 0.0, -0.0, 0.105],
+                [l0 + 4, -0.005, 0.321 - 0.13, -0.0, 0.075], [l0 + 4, 0.01, 0.321 - 0.2, -0.025, 0.055],
+                [l0 + 4, 0.01, 0.321 - 0.2, 0.025, 0.055], [l0 + 4, 0.015, 0.321 - 0.265, -0.0275, 0.05],
+                [l0 + 4, 0.015, 0.321 - 0.265, 0.0275, 0.05], [l0 + 4, 0.005, 0.321 - 0.32, -0.0225, 0.05],
+                [l0 + 4, 0.005, 0.321 - 0.32, 0.0225, 0.05],
+                [l0 + 6, 0, -0.0175, 0.0725, 0.04], [l0 + 6, 0, 0.0175, 0.0725, 0.04], [l0 + 6, 0, 0, 0.0925, 0.04],
+                [l0 + 6, 0, 0.036, 0.11, 0.04], [l0 + 6, 0, 0.027, 0.155, 0.035], [l0 + 6, 0, 0.009, 0.18, 0.03],
+                [l0 + 6, 0, 0.0095, 0.205, 0.02],
+                [l0 + 6, 0, -0.036, 0.11, 0.04], [l0 + 6, 0, -0.027, 0.155, 0.035], [l0 + 6, 0, -0.009, 0.18, 0.03],
+                [l0 + 6, 0, -0.0095, 0.205, 0.02]]
+
+    rows = base + torso + one_arm(2) + one_arm(9)
+    assert len(rows) == 65
+    return RobotModel(marm, _spheres(rows))
 
 
 def generatePointRobot(radius=1.5) -> RobotModel:

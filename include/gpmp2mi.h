@@ -32,8 +32,8 @@ extern "C" {
 #endif
 
 #define GPMP2MI_VERSION 100
-#define GPMP2MI_MAX_DOF 11      /* largest total dof a plan is instantiated for (csrc/common.h MAXD) */
-#define GPMP2MI_MAX_SPHERES 64  /* largest sphere model staged on chip */
+#define GPMP2MI_MAX_DOF 18      /* largest total dof a plan is instantiated for (csrc/common.h MAXD): the PR2 model */
+#define GPMP2MI_MAX_SPHERES 96  /* largest sphere model staged on chip (PR2: 65) */
 
 /* ---- status codes (replace the C++ exceptions of SURVEY.md section 8b "Error convention") --- */
 enum {

@@ -500,7 +500,7 @@ def test_every_tree_shape_of_the_cyclic_reduction(engine, oracle, N, opt):
 
 def test_edge_sizes_empty_long_and_many_spheres(engine, oracle):
     """edge cases: empty batches of evaluations, a single long trajectory (N = 600, beyond one wavefront of
-    blocks per level), the largest sphere model the engine stages (64), a robot entirely outside the field"""
+    blocks per level), the largest sphere model the engine stages (96), a robot entirely outside the field"""
     import gpmp2_amd as g
     p = problems.wam_restarts(B=1, total_step=600, obs_check_inter=1, opt="GN", sdf="40", max_iter=4)
     r, s, ro, so = _handles(engine, oracle, p)
@@ -521,10 +521,10 @@ def test_edge_sizes_empty_long_and_many_spheres(engine, oracle):
     assert engine.forward_kinematics(r, z7)[0].shape == (0, 7, 4, 4)
     assert engine.gp_prior_factor(7, False, 0.1, z7, z7, z7, z7)[0].shape == (0, 14)
     assert engine.sdf_query(s, np.zeros((0, 3)))[0].shape == (0,)
-    # 64 body spheres (GPMP2MI_MAX_SPHERES) on a 7-dof arm; one more is rejected
+    # 96 body spheres (GPMP2MI_MAX_SPHERES; the PR2 model has 65) on a 7-dof arm; one more is rejected
     wam = g.generateArm("WAMArm")
     rng = np.random.default_rng(77)
-    sph = [g.BodySphere(int(rng.integers(0, 7)), 0.04, tuple(rng.uniform(-0.1, 0.1, size=3))) for _ in range(64)]
+    sph = [g.BodySphere(int(rng.integers(0, 7)), 0.04, tuple(rng.uniform(-0.1, 0.1, size=3))) for _ in range(96)]
     big = g.ArmModel(wam.fk_model(), sph)
     rb, rbo = engine.robot(big), oracle.robot(big)
     q = rng.uniform(-1.5, 1.5, size=(20, 7))

@@ -271,3 +271,45 @@ def test_wide_robot_update_beyond_the_fixed_iteration_budget(engine, oracle):
     """plan created with fixed_iterations = 1, update(iterations = 5) on the 2x2-tile path (trial-step driver)"""
     from test_gpu_plan import update_beyond_budget_check
     update_beyond_budget_check(engine, oracle, _tree_problem(_wide_models()["mobile WAM (dof 10)"], N=10, inter=2, opt="GN"))
+
+
+# ------------------------------------------------------------------ 12 <= dof <= 18: the PR2 model (dense block path)
+def test_pr2_model_plans(engine, oracle):
+    """generateMobileArm('PR2') (matlab/+gpmp2/generateMobileArm.m:244-349): SE(2) base + lift + two 7-joint arms,
+    dof 18, 65 spheres -- the robot BatchTrajOptimizePose2MobileVetLin2Arms (planner/BatchTrajOptimizer.cpp:118-128) is
+    instantiated for.  Kinematics, obstacle factors, normal equations (3x3-tile export) and GN / LM / Dogleg plans
+    (dense block Cholesky) against the oracle."""
+    model = g.generateMobileArm("PR2")
+    assert model.dof() == 18 and model.nr_body_spheres() == 65
+    r, ro = engine.robot(model), oracle.robot(model)
+    rng = np.random.default_rng(41)
+    q = rng.uniform(-1.0, 1.0, size=(32, 18))
+    for fa, fb in ((engine.forward_kinematics, oracle.forward_kinematics), (engine.sphere_centers, oracle.sphere_centers)):
+        a, b = fa(r, q), fb(ro, q)
+        np.testing.assert_allclose(a[0], b[0], atol=1e-9)
+        np.testing.assert_allclose(a[1], b[1], atol=1e-9)
+    p = _tree_problem(model, N=8, inter=1, opt="GN")
+    p.end_conf[0, 3] = 0.2                                       # lift
+    p.end_conf[0, 4:] = np.tile(np.linspace(0.2, 0.8, 7), 2) * np.r_[np.ones(7), -np.ones(7)]
+    for i in range(9):
+        p.init[0, i, :18] = p.start_conf[0] * (8 - i) / 8 + p.end_conf[0] * i / 8
+    p.init[0, :, 18:] = (p.end_conf[0] - p.start_conf[0])[None, :] / 3.0
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    (ea, ha), (eb, hb) = engine.obstacle_factor(r, s, 0.6, p.init[0, :, :18]), oracle.obstacle_factor(ro, so, 0.6, p.init[0, :, :18])
+    assert (eb > 0).sum() > 5
+    np.testing.assert_allclose(ea, eb, atol=1e-9)
+    np.testing.assert_allclose(ha, hb, atol=1e-8)
+    args = (p.start_conf, p.start_vel, p.end_conf, p.end_vel)
+    traj = p.init + 0.05 * rng.normal(size=p.init.shape)
+    a = engine.linearize(r, s, p.setting, *args, traj)
+    b = oracle.linearize(ro, so, p.setting, *args, traj)
+    for x, y in zip(a[:3], b[:3]):
+        np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max())
+    np.testing.assert_allclose(a[3], b[3], rtol=1e-9)
+    for opt in ("GN", "LM", "DOGLEG"):
+        {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM, "DOGLEG": p.setting.setDogleg}[opt]()
+        res = engine.batch_optimize(r, s, p.setting, *args, p.init)
+        ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
+        assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
+        np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
+        np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
