@@ -58,39 +58,59 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
   const int c = lane & 15, g = lane >> 4;
   double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
   bool ok = true;
-  static_for<0, n>([&](auto jc) {
+  // pivot row j of the four tiles, broadcast to all four 16-lane rows (same column)
+  auto fetch_row = [&](auto jc, double& rS, double& rL, double& rR, double& rV) {
     constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
 #if G2_ROW_SWAP
-    const double rowS = bcast_row<gj>(S.r[rj]);
-    const double rowL = bcast_row<gj>(Cl.r[rj]);
-    const double rowR = bcast_row<gj>(Cr.r[rj]);
-    const double rowV = bcast_row<gj>(V.r[rj]);
+    rS = bcast_row<gj>(S.r[rj]);
+    rL = bcast_row<gj>(Cl.r[rj]);
+    rR = bcast_row<gj>(Cr.r[rj]);
+    rV = bcast_row<gj>(V.r[rj]);
 #else
     const int src = gj * 16 + c;
-    const double rowS = __shfl(S.r[rj], src, 64);
-    const double rowL = __shfl(Cl.r[rj], src, 64);
-    const double rowR = __shfl(Cr.r[rj], src, 64);
-    const double rowV = __shfl(V.r[rj], src, 64);
+    rS = __shfl(S.r[rj], src, 64);
+    rL = __shfl(Cl.r[rj], src, 64);
+    rR = __shfl(Cr.r[rj], src, 64);
+    rV = __shfl(V.r[rj], src, 64);
 #endif
+  };
+  double rowS, rowL, rowR, rowV;
+  fetch_row(std::integral_constant<int, 0>{}, rowS, rowL, rowR, rowV);
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
     const double piv = readlane_d(S.r[rj], gj * 16 + j);
     ok = ok && (piv > 0.0);
     const double inv = fast_rcp(piv);
     if (g == gj) piv_of_row[rj] = piv;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (4 * k + 3 <= j) continue;  // rows g + 4k <= j for every g: nothing below the pivot here
+    auto update = [&](int k) {
 #if G2_M_DPP
       const double m = bcast_in_row<j>(S.r[k]);
 #else
       const double m = __shfl(S.r[k], g * 16 + j, 64);
 #endif
-      // rows at or above the pivot get a zero multiplier instead of a divergent branch
-      const double f = (g + 4 * k > j) ? m * inv : 0.0;
+      // rows at or above the pivot get a zero multiplier instead of a divergent branch; registers whose four
+      // rows are all below the pivot (4 k > j) need no test
+      const double f = (4 * k > j || g + 4 * k > j) ? m * inv : 0.0;
       S.r[k] = fma(-f, rowS, S.r[k]);
       Cl.r[k] = fma(-f, rowL, Cl.r[k]);
       Cr.r[k] = fma(-f, rowR, Cr.r[k]);
       V.r[k] = fma(-f, rowV, V.r[k]);
+    };
+    // look-ahead: the register that holds the NEXT pivot row is updated first and its broadcast is issued right
+    // away, so the cross-lane latency overlaps with the updates of the remaining registers
+    constexpr int k1 = (j + 1) >> 2;
+    double nS = 0.0, nL = 0.0, nR = 0.0, nV = 0.0;
+    if constexpr (j + 1 < n) {
+      if constexpr (4 * k1 + 3 > j) update(k1);
+      fetch_row(std::integral_constant<int, j + 1>{}, nS, nL, nR, nV);
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (4 * k + 3 <= j) continue;            // rows g + 4k <= j for every g: nothing below the pivot here
+      if (j + 1 < n && k == k1) continue;      // done above
+      update(k);
+    }
+    rowS = nS; rowL = nL; rowR = nR; rowV = nV;
   });
 #pragma unroll
   for (int k = 0; k < 4; k++) {
