@@ -137,7 +137,7 @@ def pmc_traffic():
     --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same command, gfx950
     correction applied; see profiles/README.md).  A STORED profile, not a live measurement."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # the B = 64 GN profile of each round
     for f in reversed(files):
         try:
             d = json.load(open(f))
