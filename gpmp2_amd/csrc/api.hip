@@ -886,6 +886,12 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.no_increase = s->final_iter_no_increase;
   P.fixed_iters = o.fixed_iterations;
   P.end_conf_prior_off = o.end_conf_prior_off ? 1 : 0;
+  {
+    // sphere-split linearization for fixed-base arms (k_linearize NSPLIT = 2); GPMP2MI_LIN_SPLIT=1 / 2 forces either form
+    const char* e = getenv("GPMP2MI_LIN_SPLIT");
+    P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? 2 : 1;
+    if (e && (e[0] == '1' || e[0] == '2')) P.lin_split = e[0] - '0';
+  }
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
   // planner/BatchTrajOptimizer-inl.h:30-31

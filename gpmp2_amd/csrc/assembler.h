@@ -13,6 +13,13 @@
 
 namespace g2 {
 
+// diagnostic build only: phase stamps of build_tiles for block i == 1 (slots 24.. of the trajectory's stamp row)
+#ifdef G2_STAMPS
+#define G2_BSTAMP(k) do { if (i == 1 && lane == 0 && row0 == 0 && col0 == 0) pb.stamps[(size_t)b * 64 + 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define G2_BSTAMP(k) do {} while (0)
+#endif
+
 constexpr int GP_EXTRA_LIE = 18;  // J1 (9) + J3 (9) appended to the GP record of Pose2 robots
 
 template <int D, bool LIE>
@@ -190,6 +197,7 @@ struct Assembler {
     const double* J1i = si.gpr() + n + 1;
     const double* J3n = sn.gpr() + n + 1 + 9;
 
+    G2_BSTAMP(0);
     // ---------------------------------------------------------------- phase 1: row owners
     const bool need_diag = (row0 == col0), need_rhs = (rhscol >= col0 && rhscol < col0 + 16);
     const int orow = row0 + lane;                       // the row this lane owns (lanes 0..15)
@@ -293,6 +301,7 @@ struct Assembler {
       o_ee = need_diag ? ee : 0.0;
     }
 
+    G2_BSTAMP(1);
     // ---------------------------------------------------------------- phase 2: matrix entries
     double dk[4] = {0, 0, 0, 0}, hrk[4] = {0, 0, 0, 0}, hlk[4] = {0, 0, 0, 0};
     const int ac = a_col, kc = k_col;
@@ -319,6 +328,7 @@ struct Assembler {
           hlk[k] = fp * P.KO[cc_ * n + rr_];
         }
       }
+      G2_BSTAMP(2);
       if (has_prev && has_next) {
 #pragma unroll 1
         for (int jj = 0; jj < I; jj++) {
@@ -436,6 +446,7 @@ struct Assembler {
       }
     }
     }
+    G2_BSTAMP(3);
     for (int e = 0; e < nxp; e++) {
       const size_t xe = (size_t)b * XP_MAX + e;
       if (pb.xp_state[xe] != i) continue;
@@ -463,6 +474,7 @@ struct Assembler {
       Cr.r[k] = hrk[k];
       Cl.r[k] = hlk[k];
     }
+    G2_BSTAMP(4);
     return err_acc;
   }
 };

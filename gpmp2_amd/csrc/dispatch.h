@@ -53,3 +53,21 @@
       return GPMP2MI_ERR_UNSUPPORTED;                                                 \
     }                                                                                 \
   } while (0)
+
+// fixed-base arms only (kernels that exist in an extra variant for them): AD_ = number of joints
+#define G2_DISPATCH_ROBOT_ARM_ONLY(ad, STMT)                                \
+  do {                                                                      \
+    switch (ad) {                                                           \
+      case 1: { constexpr int AD_ = 1; STMT; } break;                       \
+      case 2: { constexpr int AD_ = 2; STMT; } break;                       \
+      case 3: { constexpr int AD_ = 3; STMT; } break;                       \
+      case 4: { constexpr int AD_ = 4; STMT; } break;                       \
+      case 5: { constexpr int AD_ = 5; STMT; } break;                       \
+      case 6: { constexpr int AD_ = 6; STMT; } break;                       \
+      case 7: { constexpr int AD_ = 7; STMT; } break;                       \
+      case 8: { constexpr int AD_ = 8; STMT; } break;                       \
+      default:                                                              \
+        g2::set_error("arm dof is not instantiated");                       \
+        return GPMP2MI_ERR_UNSUPPORTED;                                     \
+    }                                                                       \
+  } while (0)

@@ -16,6 +16,7 @@ struct PlanParams {
   int max_pass;
   int obs_skip_first, flag_pos_limit, flag_vel_limit, opt_type, max_iter, no_increase, fixed_iters,
       lie;
+  int lin_split;                       // 2: k_linearize splits the spheres of a point over 2 wavefronts (fixed-base arms)
   int end_conf_prior_off;              // 1: no PriorFactor on x_N (a goal / workspace factor stands in)
   int wide;                            // 2 dof > 15: dense block path (k_export_normal_eq + k_solve_dense)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step

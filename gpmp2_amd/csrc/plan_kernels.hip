@@ -29,31 +29,43 @@ namespace g2 {
 #else
 #define G2_LSTAMP(k) do {} while (0)
 #endif
-template <int KIND, int AD, int AD2, int SDIM>
-__global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
-                                                   const PlanParams* __restrict__ pp,
-                                                   PlanBuffers pb, const double* __restrict__ traj,
-                                                   int bufsel, const int* __restrict__ active) {
+// NSPLIT = 1: one wavefront per 64 evaluation points.  NSPLIT = 2 (fixed-base arms): a workgroup of two wavefronts per
+// 64 points -- both walk the kinematic chain (replicated) but each visits only the body spheres s % 2 == its index,
+// so a point's 16 serial lookup / Jacobian steps become 8; the partial records are summed through LDS (w0 += w1),
+// wavefront 0 stores the record while wavefront 1 evaluates the GP prior.  Splitting over LANES cannot work (lanes with
+// different sphere subsets diverge and take turns); splitting over four wavefronts needs <= 168 VGPRs for all
+// workgroups to be resident and spills (measured: 34.8 us against 18.1 us for two and 22.2 us for one at 64
+// trajectories).  Register budget: 2 wavefronts per SIMD (<= 256 VGPRs) for arms -- at 1 024 trajectories that alone
+// takes the unsplit kernel from 86.7 to 74.2 us, the split one to 69.3 us.
+template <int KIND, int AD, int AD2, int SDIM, int NSPLIT>
+__global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
+                                                            const PlanParams* __restrict__ pp,
+                                                            PlanBuffers pb, const double* __restrict__ traj,
+                                                            int bufsel, const int* __restrict__ active) {
   using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF, n = 2 * D, NG = D * (D + 1) / 2;
   const PlanParams& P = *pp;
   const int nchunk = P.Ppad / 64;
   const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
   if (active && !active[b]) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+#ifdef G2_WGTIMES
+  if (threadIdx.x == 0) pb.stamps[(size_t)blockIdx.x * 2] = wall_clock64();
+#endif
   double* __restrict__ rec = rec_of(pb, pb.which[b], bufsel);
   double* __restrict__ gpu = gpu_of(pb, pb.which[b], bufsel);
   G2_LSTAMP(0);
   // robot model -> LDS: the global loads are issued first and committed after the state loads and
   // the GP interpolation below, so their latency overlaps
   __shared__ RobotDev R;
-  constexpr int RN = sizeof(RobotDev) / 4, RPT = (RN + 63) / 64;
+  constexpr int NT = 64 * NSPLIT, RN = sizeof(RobotDev) / 4, RPT = (RN + NT - 1) / NT;
   int rtmp[RPT];
 #pragma unroll
   for (int u = 0; u < RPT; u++) {
-    const int idx = threadIdx.x + 64 * u;
+    const int idx = threadIdx.x + NT * u;
     rtmp[u] = idx < RN ? reinterpret_cast<const int*>(Rg)[idx] : 0;
   }
-  const int p_raw = chunk * 64 + threadIdx.x;
+  const int p_raw = chunk * 64 + lane;
   const int p = min(p_raw, P.P - 1);  // tail lanes shadow the last point until the barrier below
   const int N = P.N, I = P.I;
   int i = 0, j = I;
@@ -91,11 +103,11 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
 
 #pragma unroll
   for (int u = 0; u < RPT; u++) {
-    const int idx = threadIdx.x + 64 * u;
+    const int idx = threadIdx.x + NT * u;
     if (idx < RN) reinterpret_cast<int*>(&R)[idx] = rtmp[u];
   }
   __syncthreads();
-  if (p_raw >= P.P) return;
+  if (NSPLIT == 1 && p_raw >= P.P) return;   // (split form: tail lanes keep shadowing the last point, stores are predicated)
   G2_LSTAMP(1);
   double G[NG], gv[D], e = 0.0;
 #pragma unroll
@@ -129,12 +141,35 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
           // and the sphere's Jacobian is never formed
           return !(hx == 0.0 && hy == 0.0 && hz == 0.0 && r == 0.0);
         },
-        [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) { accumulate(Jc, nc); });
+        [&](int, const double (&)[3], const double (&Jc)[D][3], auto nc) { accumulate(Jc, nc); }, wv, NSPLIT);
   }
+  if constexpr (NSPLIT > 1) {
+    // partial records -> wavefront 0 through LDS: w0 += w1
+    static_assert(NSPLIT == 2, "two wavefronts per point set");
+    constexpr int RV = NG + D + 1;
+    __shared__ double part[RV][64];
+    if (wv == 1) {
+#pragma unroll
+      for (int k = 0; k < NG; k++) part[k][lane] = G[k];
+#pragma unroll
+      for (int k = 0; k < D; k++) part[NG + k][lane] = gv[k];
+      part[NG + D][lane] = e;
+    }
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+      for (int k = 0; k < NG; k++) G[k] += part[k][lane];
+#pragma unroll
+      for (int k = 0; k < D; k++) gv[k] += part[NG + k][lane];
+      e += part[NG + D][lane];
+    }
+  }
+  const bool store_ok = (NSPLIT == 1) || (p_raw < P.P);
   G2_LSTAMP(13);
   const double w = P.obs_w;
-  // point-major record: this lane's REC values are one contiguous run, stored in 16-B pieces
-  {
+  // point-major record: this lane's REC values are one contiguous run, stored in 16-B pieces (split form: wavefront 0
+  // holds the sums; the last wavefront takes the GP prior below, so the two tails run side by side)
+  if (NSPLIT == 1 || wv == 0) {
     constexpr int RECL = NG + D + 1 + (K::BASE == 3 ? 36 : 0);
     double rv[RECL + 1];
 #pragma unroll
@@ -153,7 +188,7 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     const int nst = P.RECS >> 1;   // REC <= RECL: mobile robots without interpolation store the short record
 #pragma unroll
     for (int k = 0; k < (RECL + 1) / 2; k++)
-      if (k < nst) rb[k] = double2{rv[2 * k], rv[2 * k + 1]};
+      if (k < nst && store_ok) rb[k] = double2{rv[2 * k], rv[2 * k + 1]};
   }
 
   G2_LSTAMP(14);
@@ -162,9 +197,18 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
   // GaussianProcessPriorLie<Pose2Vector> (gp/GaussianProcessPriorLie.h:61-86)
   // r = [Log(x1^-1 x2) - v1 dt ; v2 - v1] plus the pose blocks of its Jacobians.
   // Both: u = Q^-1 r (Q^-1 = B(dt) (x) Qc^-1), energy r^T u.
-  if (unary && i > 0) {
+  if (unary && i > 0 && store_ok && (NSPLIT == 1 || wv == NSPLIT - 1)) {
     double rx[D], rv[D], sx[D], sv[D];
     double* gb = gpu + ((size_t)b * P.Npad + i) * P.GPS;
+    if constexpr (NSPLIT > 1) {   // the states were not kept in registers across the sphere loop: fetch them again
+#pragma unroll
+      for (int k = 0; k < D; k++) {
+        x1[k] = z1[k];
+        v1[k] = z1[D + k];
+        x0[k] = z0[k];
+        v0[k] = z0[D + k];
+      }
+    }
     if constexpr (K::BASE == 3) {
       const P2 p1{x0[0], x0[1], x0[2]}, p2{x1[0], x1[1], x1[2]};
       const P2 bt = pose2_between(p1, p2);
@@ -216,21 +260,32 @@ __global__ __launch_bounds__(64) void k_linearize(const RobotDev* __restrict__ R
     gb[n] = en;
   }
   G2_LSTAMP(15);
+#ifdef G2_WGTIMES
+  if (threadIdx.x == 0) pb.stamps[(size_t)blockIdx.x * 2 + 1] = wall_clock64();
+#endif
 }
 
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
                      const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
                      hipStream_t st) {
-  // One lane per evaluation point.  (A 4-lanes-per-point variant that splits the body spheres was
-  // measured and rejected: the per-lane cost is dominated by the kinematic chain, which every lane
-  // would repeat -- 44 us vs 26 us at B = 64, no gain even at B = 1.  A two-sweep variant that kept
-  // 8 SDF lookups in flight was no faster either: the wave is fp64-issue bound, not latency bound;
-  // DESIGN.md section 4.)
-  const dim3 grid(hp.B * (hp.Ppad / 64)), block(64);
-  if (sdf.dim == 3) {
-    G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 3><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+  // One lane per evaluation point; fixed-base arms split the spheres of a point over the two wavefronts of a
+  // workgroup (NSPLIT = 2, see the kernel).  A variant that kept 4-8 SDF cells in flight per lane was no faster
+  // (DESIGN.md section 4).
+  const dim3 grid(hp.B * (hp.Ppad / 64));
+  if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
+    const dim3 block(128);
+    if (sdf.dim == 3) {
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 3, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    } else {
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 2, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    }
   } else {
-    G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    const dim3 block(64);
+    if (sdf.dim == 3) {
+      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 3, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    } else {
+      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 2, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    }
   }
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;

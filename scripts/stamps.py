@@ -17,6 +17,8 @@ for b in (0, 33):
     print('   linearize wave (b, chunk 1): [loads+interp | sphere 0..10 (FK link walk + lookup + J) | rest of spheres | stores | gp] cycles', [int(x) for x in np.diff(tl[tl > 0])])
     ta = raw[32:40]
     print('   assemble wave (b, i=1): stage/build/misc/elim/store cycles', [int(x) for x in np.diff(ta[:6])])
+    tb = raw[24:29]
+    print('   build_tiles (b, i=1): owner rows / constants + unary / sub-step loop / replanner priors + shuffles', [int(x) for x in np.diff(tb)])
     t2 = raw[40:48]
     print('   assemble wave (b, i=2, level 2): stage/build/-/-/-/wait for odd blocks/level-2 products+elim+store', [int(x) for x in np.diff(t2[t2 > 0])])
     print('   assemble i=1 start -> i=2 end:', int(raw[47] - raw[32]))
