@@ -166,8 +166,12 @@ __device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane)
 // their Schur complements (handed over through LDS), gets its fill-in couplings to 4q and 4q + 4 and is
 // eliminated too.  The per-trajectory solve kernels start at level 4 (cr_forward).
 constexpr int ASM_WAVES = 4;
+// register budget of k_assemble: wavefronts per SIMD the kernel must leave room for (5 -> <= 96 VGPRs)
+#ifndef G2_ASM_MINW
+#define G2_ASM_MINW 5
+#endif
 template <int D, bool LIE>
-__global__ __launch_bounds__(64 * ASM_WAVES) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
+__global__ __launch_bounds__(64 * ASM_WAVES, G2_ASM_MINW) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                               const double* __restrict__ traj, int bufsel,
                                                               double* __restrict__ tiles,
                                                               const int* __restrict__ active) {
@@ -432,19 +436,39 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
+  // the factor tiles of a wavefront's first task of a level do not depend on the level above: they are requested
+  // BEFORE the barrier that publishes that level's solutions, so their latency hides behind it
+  auto block_of = [&](int h, int idx) { return (h == hfinal) ? 0 : h * (2 * idx + 1); };
+  auto count_of = [&](int h) { return (h == hfinal) ? 1 : ((N / h) + 1) / 2; };
+  Tile pWl = tile_zero(), pWr = tile_zero(), pV = tile_zero();
+  auto prefetch = [&](int h) {
+    if (h >= hmin && w < count_of(h)) {
+      const double* f = fac + (size_t)block_of(h, w) * 3 * TILE_DBL;
+      pWl = tile_load(f, lane);
+      pWr = tile_load(f + TILE_DBL, lane);
+      pV = tile_load(f + 2 * TILE_DBL, lane);
+    }
+  };
+  prefetch(hfinal);
   for (int h = hfinal; h >= hmin; h >>= 1) {
     const bool final = (h == hfinal);
-    const int count = final ? 1 : ((N / h) + 1) / 2;
+    const int count = count_of(h);
     for (int idx = w; idx < count; idx += CR_WAVES) {
-      const int j = final ? 0 : h * (2 * idx + 1);
-      const double* f = fac + (size_t)j * 3 * TILE_DBL;
-      const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
+      const int j = block_of(h, idx);
+      Tile Wl = pWl, Wr = pWr, V = pV;
+      if (idx != w) {
+        const double* f = fac + (size_t)j * 3 * TILE_DBL;
+        Wl = tile_load(f, lane);
+        Wr = tile_load(f + TILE_DBL, lane);
+        V = tile_load(f + 2 * TILE_DBL, lane);
+      }
       const int jl = j - h, jr = j + h;
       const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
       const double xr = (!final && jr <= N) ? xs[jr * 16 + c] : 0.0;
       const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
       if (g == 0) xs[j * 16 + c] = (c < n) ? x : 0.0;
     }
+    prefetch(h >> 1);
     __syncthreads();
     G2_STAMP(16 + __builtin_ctz(h));  // 16.. : after backward level h
   }
@@ -587,15 +611,23 @@ __global__ __launch_bounds__(256) void k_finish_step(const PlanParams* __restric
   const int groups = (N + 4) / 4;
   const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
   if (pb.stepped[b] != pass + 1) return;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int i = 4 * q + wv;
   const bool live = i <= N;
   __shared__ double xl_[4][16];
   const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  // every wavefront that has a block to solve (4q+2 at level 2, the odd ones at level 1) requests its three factor
+  // tiles and its old state right away, so the level-1 loads are in flight while level 2 is being solved
+  const bool has_block = live && wv != 0;
+  Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
+  if (has_block) {
+    const double* f = fac + (size_t)i * 3 * TILE_DBL;
+    Wl = tile_load(f, lane);
+    Wr = tile_load(f + TILE_DBL, lane);
+    V = tile_load(f + 2 * TILE_DBL, lane);
+  }
   auto solve = [&](int j, int h) {
-    const double* f = fac + (size_t)j * 3 * TILE_DBL;
-    const Tile Wl = tile_load(f, lane), Wr = tile_load(f + TILE_DBL, lane), V = tile_load(f + 2 * TILE_DBL, lane);
     const int jl = j - h, jr = j + h;
     auto xof = [&](int m) { return (m & 3) ? xl_[m & 3][c] : xg[(size_t)m * 16 + c]; };
     const double xl = (jl >= 0) ? xof(jl) : 0.0;
