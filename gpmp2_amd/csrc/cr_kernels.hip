@@ -81,7 +81,6 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
     const double piv = readlane_d(S.r[rj], gj * 16 + j);
     ok = ok && (piv > 0.0);
     const double inv = fast_rcp(piv);
-    if (g == gj) piv_of_row[rj] = piv;
     auto update = [&](int k) {
 #if G2_M_DPP
       const double m = bcast_in_row<j>(S.r[k]);
@@ -112,6 +111,14 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
     }
     rowS = nS; rowL = nL; rowR = nR; rowV = nV;
   });
+  // the pivots are what is left on the diagonal (row j is final once pivot j has been applied): one gather per
+  // register instead of two selects per pivot inside the loop
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int rho = g + 4 * k;
+    const double d = __shfl(S.r[k], g * 16 + (rho & 15), 64);
+    piv_of_row[k] = (rho < n) ? d : 1.0;
+  }
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const double s = fast_rsqrt(piv_of_row[k]);

@@ -64,16 +64,18 @@ __device__ __forceinline__ double bcast_row(double v) {
                           (int)bcast_row_u32<G>((unsigned)__double2loint(v)));
 }
 // value held by lane J of each row, broadcast inside that row (DPP row_newbcast:J)
+// (mov_dpp, not update_dpp(0, ...): with all rows and banks enabled every lane is written, so there is no "old" value
+// to keep -- update_dpp with old = 0 costs a v_mov 0 per dword in front of every DPP move)
 template <int J>
 __device__ __forceinline__ double bcast_in_row(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x150 + J, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x150 + J, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 template <int R>
 __device__ __forceinline__ double dpp_row_ror(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + R, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + R, 0xF, 0xF, false);
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0x120 + R, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0x120 + R, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 // sum over the 16 lanes of each row, result in every lane of the row
