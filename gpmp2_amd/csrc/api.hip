@@ -976,6 +976,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
+  G2_TRY(plan_alloc(p.get(), &pb.spart, (size_t)B * ((P.N + 4) / 4) * 3));
   G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * 16));
   if (wide) {
     G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
@@ -1240,6 +1241,10 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
         }
         p->timer.begin("solve_step", st);
         G2_TRY(launch_solve_step(P, pb, st));
+        if (P.split_back && P.opt_type != GPMP2MI_OPT_DOGLEG) {   // LM / GN: levels 2, 1, step and trial point chip-wide
+          p->timer.begin("finish_trial", st);
+          G2_TRY(launch_finish_trial(P, pb, st));
+        }
       }
       p->timer.begin("linearize", st);
       G2_TRY(plan_linearize(p, pb.trial, 1, pb.active, st));

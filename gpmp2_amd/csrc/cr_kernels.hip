@@ -672,6 +672,86 @@ int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hi
   return GPMP2MI_OK;
 }
 
+// Chip-wide tail of an LM / GN trial step (split form of k_solve_step): as k_finish_step, but the step goes to
+// `delta`, the trial point cur (+) delta to `trial` (cur stays), and every workgroup leaves its share of g.delta,
+// |delta|^2, |g|^2 in spart for the step control (k_decide sums them in group order).
+template <int D>
+__global__ __launch_bounds__(256) void k_finish_trial(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int groups = (N + 4) / 4;
+  const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
+  if (!pb.active[b] || pb.stepped[b] != 1) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int i = 4 * q + wv;
+  const bool live = i <= N;
+  __shared__ double xl_[4][16];
+  __shared__ double psum[4][3];
+  const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  const bool has_block = live && wv != 0;
+  Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
+  if (has_block) {
+    const double* f = fac + (size_t)i * 3 * TILE_DBL;
+    Wl = tile_load(f, lane);
+    Wr = tile_load(f + TILE_DBL, lane);
+    V = tile_load(f + 2 * TILE_DBL, lane);
+  }
+  auto solve = [&](int j, int h) {
+    const int jl = j - h, jr = j + h;
+    auto xof = [&](int m) { return (m & 3) ? xl_[m & 3][c] : xg[(size_t)m * 16 + c]; };
+    const double xl = (jl >= 0) ? xof(jl) : 0.0;
+    const double xr = (jr <= N) ? xof(jr) : 0.0;
+    const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+    if (g == 0) xl_[j & 3][c] = (c < n) ? x : 0.0;
+  };
+  if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(4 * q) * 16 + lane];
+  if (wv == 2 && live) solve(i, 2);
+  __syncthreads();
+  if ((wv & 1) && live) solve(i, 1);
+  __syncthreads();
+  double gd = 0.0, dd = 0.0, gg = 0.0;
+  if (live && lane < n) {
+    const size_t k = ((size_t)b * (N + 1) + i) * n + lane;
+    const double* zs = pb.cur + ((size_t)b * (N + 1) + i) * n;
+    const double x = xl_[wv][lane], gk = pb.gvec[((size_t)b * (N + 1) + i) * 16 + lane];
+    pb.delta[k] = x;
+    pb.trial[k] = (lane < D) ? retract_coord(P.lie != 0, lane, zs, xl_[wv]) : zs[lane] + x;
+    gd = gk * x;
+    dd = x * x;
+    gg = gk * gk;
+  }
+  gd = wave_sum(gd);
+  dd = wave_sum(dd);
+  gg = wave_sum(gg);
+  if (lane == 0) {
+    psum[wv][0] = gd;
+    psum[wv][1] = dd;
+    psum[wv][2] = gg;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int t = threadIdx.x;
+    pb.spart[((size_t)b * groups + q) * 3 + t] = ((psum[0][t] + psum[1][t]) + psum[2][t]) + psum[3][t];
+  }
+}
+
+int launch_finish_trial(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B * ((hp.N + 4) / 4)), block(256);
+  switch (hp.D) {
+#define G2_FINT_CASE(DD) \
+  case DD: k_finish_trial<DD><<<grid, block, 0, st>>>(pb.params, pb); break;
+    G2_FINT_CASE(1) G2_FINT_CASE(2) G2_FINT_CASE(3) G2_FINT_CASE(4) G2_FINT_CASE(5) G2_FINT_CASE(6) G2_FINT_CASE(7)
+#undef G2_FINT_CASE
+    default:
+      set_error("block solver is instantiated for dof <= 7");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {
   const dim3 grid(hp.B), block(64 * CR_WAVES);
   const size_t shmem = ((size_t)(hp.N + 1) * 16 + CR_WAVES + 2) * sizeof(double);
@@ -732,7 +812,10 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* 
   int* flags = reinterpret_cast<int*>(red + CR_WAVES);
   const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
   const bool resolve = !(dogleg && pb.phase[b] != 0);
-  if (tid == 0) flags[1] = 0;
+  if (tid == 0) {
+    flags[1] = 0;
+    pb.stepped[b] = 0;   // set again once the factorisation has succeeded (split form)
+  }
   __syncthreads();
   if (resolve) {
     const bool ok = cr_forward<n>(pb, b, N, tid);
@@ -740,6 +823,15 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* 
     __syncthreads();
     if (flags[1]) {
       if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
+      return;
+    }
+    if (P.split_back && !dogleg) {
+      // LM / GN: as on the Gauss-Newton fast path only the blocks that are multiples of 4 are back-substituted
+      // here; levels 2, 1, the step, the trial point and the step-control sums follow chip-wide in k_finish_trial
+      cr_backward<n>(pb, b, N, tid, xs, 4);
+      double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+      for (int k = tid; k < (N / 4 + 1) * 16; k += blockDim.x) xg[(size_t)(k >> 4) * 64 + (k & 15)] = xs[(k >> 4) * 64 + (k & 15)];
+      if (tid == 0) pb.stepped[b] = 1;
       return;
     }
     cr_backward<n>(pb, b, N, tid, xs);

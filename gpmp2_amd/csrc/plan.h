@@ -98,7 +98,9 @@ struct PlanBuffers {
   double* wHo;             // [B][N][n][n]     block (i+1, i), then W_i = R_i^-T H_{i,i+1}
   double* wg;              // [B][N+1][n]      gradient, then y_i
   double* xg;              // [B][N+1][16] step of the blocks the solve kernel back-substitutes itself (split path)
-  int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path)
+  int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path); trial-step
+                           // path: 1 when k_solve_step left a factorisation for k_finish_trial
+  double* spart;           // [B][ceil((N+1)/4)][3] per-group shares of g.delta, |delta|^2, |g|^2 (k_finish_trial)
   int* which;              // [B] record buffer (0: rec/gpu, 1: rec2/gpu2) holding the linearization at `cur`
   // per-trajectory scalars
   double* cur_err;         // error at `cur`
@@ -145,6 +147,7 @@ int launch_finalize_unfinished(const PlanParams& hp, const PlanBuffers& pb, hipS
 int launch_debug_crosslane(const double* in, double* out, hipStream_t st);
 int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
+int launch_finish_trial(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 // wide_cr.h (8 <= dof <= 11 on 2x2 tiles)
 int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,

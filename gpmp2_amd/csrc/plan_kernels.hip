@@ -435,6 +435,20 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
     }
   } else if (w0) {
     const double new_err = err_sum;
+    // LM / GN split form: g.delta, |delta|^2, |g|^2 arrive as per-group shares of k_finish_trial (fixed-order wave sums)
+    double sp_gd = 0.0, sp_dd = 0.0, sp_gg = 0.0;
+    if (P.split_back && P.opt_type == GPMP2MI_OPT_LM && !failed) {
+      const int groups = (N + 4) / 4;
+      const double* sp = pb.spart + (size_t)b * groups * 3;
+      for (int qq = lane; qq < groups; qq += 64) {
+        sp_gd += sp[3 * qq];
+        sp_dd += sp[3 * qq + 1];
+        sp_gg += sp[3 * qq + 2];
+      }
+      sp_gd = wave_sum(sp_gd);
+      sp_dd = wave_sum(sp_dd);
+      sp_gg = wave_sum(sp_gg);
+    }
     if (lane == 0) {
       pb.notspd[b] = 0;
       const double cur_err = pb.cur_err[b];
@@ -449,6 +463,11 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
         bool step_ok = false, stop = false;
         if (!failed) {
           const double old_lin = cur_err;
+          if (P.split_back) {   // per-group shares of k_finish_trial, summed by wavefront 0 above
+            sc[SC_GD] = sp_gd;
+            sc[SC_DD] = sp_dd;
+            sc[SC_GG] = sp_gg;
+          }
           const double lin_change = -(0.5 * sc[SC_GD] - 0.5 * lambda * sc[SC_DD]);
           if (lin_change >= 0) {
             const double cost_change = cur_err - new_err;
