@@ -63,11 +63,6 @@ struct PlanExtras {
   double* sc_H;      // [M][n_sc][D]
 };
 
-// the sizes k_linearize needs in its first instructions, passed by value
-struct LinDims {
-  int Ppad, P, N, I;
-};
-
 // Per-plan device buffers.
 struct PlanBuffers {
   PlanParams* params;      // device copy

@@ -41,21 +41,19 @@ template <int KIND, int AD, int AD2, int SDIM, int NSPLIT>
 __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) void k_linearize(const RobotDev* __restrict__ Rg, SdfDev sdf,
                                                             const PlanParams* __restrict__ pp,
                                                             PlanBuffers pb, const double* __restrict__ traj,
-                                                            int bufsel, const int* __restrict__ active, LinDims dims) {
-  // `dims` carries the sizes the first instructions need BY VALUE (kernel-argument SGPRs): with them behind `pp` the
-  // prologue is a chain of dependent memory round trips (kernarg -> pp->Ppad -> active[b] -> states); this way the
-  // activity flag, the robot model and the states are all requested right away and the early exit comes after
+                                                            int bufsel, const int* __restrict__ active) {
   using K = Kin<KIND, AD, AD2>;
   constexpr int D = K::DOF, n = 2 * D, NG = D * (D + 1) / 2;
   const PlanParams& P = *pp;
-  const int nchunk = dims.Ppad / 64;
+  const int nchunk = P.Ppad / 64;
   const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
-  const int act = active ? active[b] : 1;
+  if (active && !active[b]) return;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 #ifdef G2_WGTIMES
   if (threadIdx.x == 0) pb.stamps[(size_t)blockIdx.x * 2] = wall_clock64();
 #endif
-  const int whb = pb.which[b];
+  double* __restrict__ rec = rec_of(pb, pb.which[b], bufsel);
+  double* __restrict__ gpu = gpu_of(pb, pb.which[b], bufsel);
   G2_LSTAMP(0);
   // robot model -> LDS: the global loads are issued first and committed after the state loads and
   // the GP interpolation below, so their latency overlaps
@@ -68,8 +66,8 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
     rtmp[u] = idx < RN ? reinterpret_cast<const int*>(Rg)[idx] : 0;
   }
   const int p_raw = chunk * 64 + lane;
-  const int p = min(p_raw, dims.P - 1);  // tail lanes shadow the last point until the barrier below
-  const int N = dims.N, I = dims.I;
+  const int p = min(p_raw, P.P - 1);  // tail lanes shadow the last point until the barrier below
+  const int N = P.N, I = P.I;
   int i = 0, j = I;
   if (p > 0) {
     const int t = p - 1;
@@ -87,9 +85,6 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
     x0[k] = (i > 0) ? z0[k] : 0.0;
     v0[k] = (i > 0) ? z0[D + k] : 0.0;
   }
-  if (!act) return;   // (after the loads above have been issued; reading the states of a finished trajectory is harmless)
-  double* __restrict__ rec = rec_of(pb, whb, bufsel);
-  double* __restrict__ gpu = gpu_of(pb, whb, bufsel);
   double Mlie[4][9];
   bool lie_interp = false;
   if (unary) {
@@ -277,20 +272,19 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   // workgroup (NSPLIT = 2, see the kernel).  A variant that kept 4-8 SDF cells in flight per lane was no faster
   // (DESIGN.md section 4).
   const dim3 grid(hp.B * (hp.Ppad / 64));
-  const LinDims dims{hp.Ppad, hp.P, hp.N, hp.I};
   if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(128);
     if (sdf.dim == 3) {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 3, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dims)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 3, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
     } else {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 2, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dims)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 2, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
     }
   } else {
     const dim3 block(64);
     if (sdf.dim == 3) {
-      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 3, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dims)));
+      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 3, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
     } else {
-      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 2, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dims)));
+      G2_DISPATCH_ROBOT_H(h, (k_linearize<KIND_, AD_, AD2_, 2, 1><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
     }
   }
   G2_HIP(hipGetLastError());
