@@ -10,7 +10,7 @@ eng = engine.Engine()
 model = g.generateMobileArm("PR2")
 origin, cell, data = problems.small3d_sdf(40)
 origin, cell, data = list(np.array(origin) * 3), cell * 3, data * 3
-D, N, B = 18, 50, 16
+D, N, B = 18, 50, int(sys.argv[1]) if len(sys.argv) > 1 else 16
 for opt in ("GN", "LM"):
     st = TrajOptimizerSetting(D)
     st.set_total_step(N); st.set_total_time(10.0); st.set_obs_check_inter(2); st.set_cost_sigma(0.1); st.set_epsilon(0.4)
