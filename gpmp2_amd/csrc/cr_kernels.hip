@@ -30,6 +30,21 @@ __device__ __forceinline__ void tile_store(double* p, const Tile& T, int lane) {
 #pragma unroll
   for (int k = 0; k < 4; k++) p[k * 64 + lane] = T.r[k];
 }
+// the same for tiles whose rows >= n are structurally zero (factor and diagonal tiles of the cyclic reduction): the
+// padding rows are neither written nor read, a load leaves zeros there
+template <int n>
+__device__ __forceinline__ Tile tile_load_rows(const double* p, int lane) {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = ((lane >> 4) + 4 * k < n) ? p[k * 64 + lane] : 0.0;
+  return T;
+}
+template <int n>
+__device__ __forceinline__ void tile_store_rows(double* p, const Tile& T, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((lane >> 4) + 4 * k < n) p[k * 64 + lane] = T.r[k];
+}
 __device__ __forceinline__ Tile tile_zero() {
   Tile T;
 #pragma unroll
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES, G2_ASM_MINW) void k_assemble(const 
         if (g + 4 * k == c && c < n) S.r[k] += lam;
     }
     if (!odd) {
-      if (!lvl2) tile_store(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
+      if (!lvl2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
     } else {
       // level h = 1: odd blocks only couple to their (even) neighbours
       Tile V;
@@ -245,9 +260,9 @@ __global__ __launch_bounds__(64 * ASM_WAVES, G2_ASM_MINW) void k_assemble(const 
       const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
       G2_ASTAMP(4);
       double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
-      tile_store(f, Cl, lane);
-      tile_store(f + TILE_DBL, Cr, lane);
-      tile_store(f + 2 * TILE_DBL, V, lane);
+      tile_store_rows<n>(f, Cl, lane);
+      tile_store_rows<n>(f + TILE_DBL, Cr, lane);
+      tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
       if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2
         double* x = xch + (size_t)(wv >> 1) * 2 * TILE_DBL;
         tile_store(x, Cl, lane);
@@ -283,9 +298,9 @@ __global__ __launch_bounds__(64 * ASM_WAVES, G2_ASM_MINW) void k_assemble(const 
     for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
     const bool ok = tile_eliminate3<n>(S, C2l, C2r, V, lane);
     double* f = pb.fac + ((size_t)b * (N + 1) + j) * 3 * TILE_DBL;
-    tile_store(f, C2l, lane);
-    tile_store(f + TILE_DBL, C2r, lane);
-    tile_store(f + 2 * TILE_DBL, V, lane);
+    tile_store_rows<n>(f, C2l, lane);
+    tile_store_rows<n>(f + TILE_DBL, C2r, lane);
+    tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
     G2_ASTAMP(7);
   }
@@ -396,17 +411,17 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       const bool em = jm >= 0, ep = jp <= N;
       const bool cm = em && elim && !final, cp = ep && elim && !final && j + h <= N;
       auto facp = [&](int blk, int which) { return fac + ((size_t)blk * 3 + which) * TILE_DBL; };
-      Tile S = tile_load(tiles + (size_t)j * TILE_DBL, lane);
+      Tile S = tile_load_rows<n>(tiles + (size_t)j * TILE_DBL, lane);
       Tile T1m = tile_zero(), T1p = tile_zero(), T2m = tile_zero(), T2p = tile_zero();
       Tile Wr_m = tile_zero(), Wl_m = tile_zero(), Wl_p = tile_zero(), Wr_p = tile_zero();
-      if (e1m) T1m = tile_load(facp(j - 1, 1), lane);
-      if (e1p) T1p = tile_load(facp(j + 1, 0), lane);
-      if (e2m) T2m = tile_load(facp(j - 2, 1), lane);
-      if (e2p) T2p = tile_load(facp(j + 2, 0), lane);
-      if (em) Wr_m = tile_load(facp(jm, 1), lane);
-      if (cm) Wl_m = tile_load(facp(jm, 0), lane);
-      if (ep) Wl_p = tile_load(facp(jp, 0), lane);
-      if (cp) Wr_p = tile_load(facp(jp, 1), lane);
+      if (e1m) T1m = tile_load_rows<n>(facp(j - 1, 1), lane);
+      if (e1p) T1p = tile_load_rows<n>(facp(j + 1, 0), lane);
+      if (e2m) T2m = tile_load_rows<n>(facp(j - 2, 1), lane);
+      if (e2p) T2p = tile_load_rows<n>(facp(j + 2, 0), lane);
+      if (em) Wr_m = tile_load_rows<n>(facp(jm, 1), lane);
+      if (cm) Wl_m = tile_load_rows<n>(facp(jm, 0), lane);
+      if (ep) Wl_p = tile_load_rows<n>(facp(jp, 0), lane);
+      if (cp) Wr_p = tile_load_rows<n>(facp(jp, 1), lane);
       Tile Cl = tile_zero(), Cr = tile_zero();
       if (e1m) schur_sub<n>(S, T1m, lane);
       if (e1p) schur_sub<n>(S, T1p, lane);
@@ -417,7 +432,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       if (ep) schur_sub<n>(S, Wl_p, lane);
       if (cp) Cr = coupling<n>(Wl_p, Wr_p, lane);  // rows j, cols j + h
       if (!elim) {
-        tile_store(tiles + (size_t)j * TILE_DBL, S, lane);
+        tile_store_rows<n>(tiles + (size_t)j * TILE_DBL, S, lane);
         continue;
       }
       Tile V;
@@ -425,9 +440,9 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
       ok = tile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
       double* f = fac + (size_t)j * 3 * TILE_DBL;
-      tile_store(f, Cl, lane);
-      tile_store(f + TILE_DBL, Cr, lane);
-      tile_store(f + 2 * TILE_DBL, V, lane);
+      tile_store_rows<n>(f, Cl, lane);
+      tile_store_rows<n>(f + TILE_DBL, Cr, lane);
+      tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
     }
     __syncthreads();
     G2_STAMP(5 + __builtin_ctz(h));   // 6.. : after level h = 2, 4, ...
@@ -451,9 +466,9 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
   auto prefetch = [&](int h) {
     if (h >= hmin && w < count_of(h)) {
       const double* f = fac + (size_t)block_of(h, w) * 3 * TILE_DBL;
-      pWl = tile_load(f, lane);
-      pWr = tile_load(f + TILE_DBL, lane);
-      pV = tile_load(f + 2 * TILE_DBL, lane);
+      pWl = tile_load_rows<n>(f, lane);
+      pWr = tile_load_rows<n>(f + TILE_DBL, lane);
+      pV = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
     }
   };
   prefetch(hfinal);
@@ -465,9 +480,9 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
       Tile Wl = pWl, Wr = pWr, V = pV;
       if (idx != w) {
         const double* f = fac + (size_t)j * 3 * TILE_DBL;
-        Wl = tile_load(f, lane);
-        Wr = tile_load(f + TILE_DBL, lane);
-        V = tile_load(f + 2 * TILE_DBL, lane);
+        Wl = tile_load_rows<n>(f, lane);
+        Wr = tile_load_rows<n>(f + TILE_DBL, lane);
+        V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
       }
       const int jl = j - h, jr = j + h;
       const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
@@ -630,9 +645,9 @@ __global__ __launch_bounds__(256) void k_finish_step(const PlanParams* __restric
   Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
   if (has_block) {
     const double* f = fac + (size_t)i * 3 * TILE_DBL;
-    Wl = tile_load(f, lane);
-    Wr = tile_load(f + TILE_DBL, lane);
-    V = tile_load(f + 2 * TILE_DBL, lane);
+    Wl = tile_load_rows<n>(f, lane);
+    Wr = tile_load_rows<n>(f + TILE_DBL, lane);
+    V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
   }
   auto solve = [&](int j, int h) {
     const int jl = j - h, jr = j + h;
@@ -694,9 +709,9 @@ __global__ __launch_bounds__(256) void k_finish_trial(const PlanParams* __restri
   Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
   if (has_block) {
     const double* f = fac + (size_t)i * 3 * TILE_DBL;
-    Wl = tile_load(f, lane);
-    Wr = tile_load(f + TILE_DBL, lane);
-    V = tile_load(f + 2 * TILE_DBL, lane);
+    Wl = tile_load_rows<n>(f, lane);
+    Wr = tile_load_rows<n>(f + TILE_DBL, lane);
+    V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
   }
   auto solve = [&](int j, int h) {
     const int jl = j - h, jr = j + h;

@@ -26,6 +26,30 @@ __device__ __forceinline__ void wtile_store(double* p, const WTile& W, int lane)
 #pragma unroll
   for (int q = 0; q < 4; q++) tile_store(p + q * TILE_DBL, W.t[q >> 1][q & 1], lane);
 }
+// the same for blocks whose rows >= n are structurally zero (diagonal and factor blocks of the reduction): the
+// padding rows are neither written nor read
+template <int n>
+__device__ __forceinline__ WTile wtile_load_rows(const double* p, int lane) {
+  WTile W;
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (16 * (q >> 1) + 4 * k >= n) { W.t[q >> 1][q & 1].r[k] = 0.0; continue; }
+      W.t[q >> 1][q & 1].r[k] = (16 * (q >> 1) + (lane >> 4) + 4 * k < n) ? p[q * TILE_DBL + k * 64 + lane] : 0.0;
+    }
+  return W;
+}
+template <int n>
+__device__ __forceinline__ void wtile_store_rows(double* p, const WTile& W, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (16 * (q >> 1) + 4 * k >= n) continue;
+      if (16 * (q >> 1) + (lane >> 4) + 4 * k < n) p[q * TILE_DBL + k * 64 + lane] = W.t[q >> 1][q & 1].r[k];
+    }
+}
 __device__ __forceinline__ WTile wtile_zero() {
   WTile W;
 #pragma unroll
@@ -41,13 +65,17 @@ __device__ __forceinline__ WTile wtile_identity(int lane) {
 }
 
 // (A^T B)(i, j) = sum_k A(k, i)^T B(k, j) over the two tile rows
+// (nrows: rows >= nrows of both operands are zero, their k-chunks are skipped)
+template <int nrows = 32>
 __device__ __forceinline__ Tile wtile_atb_ij(const WTile& A, const WTile& B, int i, int j) {
   v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int kt = 0; kt < 2; kt++)
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
+      if (16 * kt + 4 * k >= nrows) continue;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.t[kt][i].r[k], B.t[kt][j].r[k], acc, 0, 0, 0);
+    }
   Tile T;
 #pragma unroll
   for (int k = 0; k < 4; k++) T.r[k] = acc[k];
@@ -63,7 +91,7 @@ __device__ __forceinline__ void wschur_sub(WTile& S, const WTile& A, int lane) {
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
       if (16 * ti >= n) continue;
-      const Tile T = wtile_atb_ij(A, A, ti, tj);
+      const Tile T = wtile_atb_ij<n>(A, A, ti, tj);
       const int col = 16 * tj + c;
 #pragma unroll
       for (int k = 0; k < 4; k++)
@@ -80,7 +108,7 @@ __device__ __forceinline__ WTile wcoupling(const WTile& A, const WTile& B, int l
 #pragma unroll
     for (int tj = 0; tj < 2; tj++) {
       if (16 * ti >= n || 16 * tj >= n) continue;
-      const Tile T = wtile_atb_ij(A, B, ti, tj);
+      const Tile T = wtile_atb_ij<n>(A, B, ti, tj);
 #pragma unroll
       for (int k = 0; k < 4; k++)
         C.t[ti][tj].r[k] = ((16 * ti + g + 4 * k) < n && (16 * tj + c) < n) ? -T.r[k] : 0.0;
@@ -118,6 +146,7 @@ __device__ __forceinline__ bool wtile_eliminate3(WTile& S, WTile& Cl, WTile& Cr,
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         if (tr == tp && 4 * k + 3 <= jl) continue;  // rows of this register are all at or above the pivot
+        if (16 * tr + 4 * k >= n) continue;         // ... or all padding
         const double m = bcast_in_row<jl>(S.t[tr][tp].r[k]);
         const double f = (16 * tr + g + 4 * k > j) ? m * inv : 0.0;
 #pragma unroll
@@ -134,6 +163,7 @@ __device__ __forceinline__ bool wtile_eliminate3(WTile& S, WTile& Cl, WTile& Cr,
   for (int tr = 0; tr < 2; tr++)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      if (16 * tr + 4 * k >= n) continue;
       const double s = 1.0 / sqrt(piv_of_row[tr][k]);
       const double y = S.t[tr][1].r[k] * s;  // meaningful in the rhs column only
 #pragma unroll
@@ -158,6 +188,7 @@ __device__ __forceinline__ void wcr_backsolve(const WTile& Wl, const WTile& Wr, 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       double acc = 0.0;
+      if (16 * tr + 4 * k >= n) { t[tr][k] = 0.0; continue; }
 #pragma unroll
       for (int tc = 0; tc < 2; tc++) {
         const int col = 16 * tc + c;
@@ -229,14 +260,14 @@ __global__ __launch_bounds__(64) void k_assemble_wide(const PlanParams* __restri
         if (g + 4 * k == c && 16 * ti + c < n) S.t[ti][ti].r[k] += lam;
   }
   if (!odd) {
-    wtile_store(pb.tiles + ((size_t)b * (N + 1) + i) * WTILE_DBL, S, lane);
+    wtile_store_rows<n>(pb.tiles + ((size_t)b * (N + 1) + i) * WTILE_DBL, S, lane);
   } else {
     WTile V = wtile_identity(lane);
     const bool ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane);
     double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * WTILE_DBL;
-    wtile_store(f, Cl, lane);
-    wtile_store(f + WTILE_DBL, Cr, lane);
-    wtile_store(f + 2 * WTILE_DBL, V, lane);
+    wtile_store_rows<n>(f, Cl, lane);
+    wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
+    wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
   }
 }
@@ -326,35 +357,35 @@ __device__ __forceinline__ bool wcr_forward(const PlanBuffers& pb, int b, int N,
     for (int idx = w; idx < countE + countU; idx += WCR_WAVES) {
       const bool elim = idx < countE;
       const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
-      WTile S = wtile_load(tiles + (size_t)j * WTILE_DBL, lane);
+      WTile S = wtile_load_rows<n>(tiles + (size_t)j * WTILE_DBL, lane);
       WTile Cl = wtile_zero(), Cr = wtile_zero();
       const int jm = j - hh, jp = j + hh;
       if (jm >= 0) {
-        const WTile Wr = wtile_load(fac + ((size_t)jm * 3 + 1) * WTILE_DBL, lane);
+        const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jm * 3 + 1) * WTILE_DBL, lane);
         wschur_sub<n>(S, Wr, lane);
         if (elim && !final) {
-          const WTile Wl = wtile_load(fac + (size_t)jm * 3 * WTILE_DBL, lane);
+          const WTile Wl = wtile_load_rows<n>(fac + (size_t)jm * 3 * WTILE_DBL, lane);
           Cl = wcoupling<n>(Wr, Wl, lane);  // rows j, cols j - h
         }
       }
       if (jp <= N) {
-        const WTile Wl = wtile_load(fac + (size_t)jp * 3 * WTILE_DBL, lane);
+        const WTile Wl = wtile_load_rows<n>(fac + (size_t)jp * 3 * WTILE_DBL, lane);
         wschur_sub<n>(S, Wl, lane);
         if (elim && !final && j + h <= N) {
-          const WTile Wr = wtile_load(fac + ((size_t)jp * 3 + 1) * WTILE_DBL, lane);
+          const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jp * 3 + 1) * WTILE_DBL, lane);
           Cr = wcoupling<n>(Wl, Wr, lane);  // rows j, cols j + h
         }
       }
       if (!elim) {
-        wtile_store(tiles + (size_t)j * WTILE_DBL, S, lane);
+        wtile_store_rows<n>(tiles + (size_t)j * WTILE_DBL, S, lane);
         continue;
       }
       WTile V = wtile_identity(lane);
       ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
       double* f = fac + (size_t)j * 3 * WTILE_DBL;
-      wtile_store(f, Cl, lane);
-      wtile_store(f + WTILE_DBL, Cr, lane);
-      wtile_store(f + 2 * WTILE_DBL, V, lane);
+      wtile_store_rows<n>(f, Cl, lane);
+      wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
+      wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
     }
     __syncthreads();
   }
@@ -373,7 +404,7 @@ __device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N
     for (int idx = w; idx < count; idx += WCR_WAVES) {
       const int j = final ? 0 : h * (2 * idx + 1);
       const double* f = fac + (size_t)j * 3 * WTILE_DBL;
-      const WTile Wl = wtile_load(f, lane), Wr = wtile_load(f + WTILE_DBL, lane), V = wtile_load(f + 2 * WTILE_DBL, lane);
+      const WTile Wl = wtile_load_rows<n>(f, lane), Wr = wtile_load_rows<n>(f + WTILE_DBL, lane), V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
       const int jl = j - h, jr = j + h;
       double xl[2], xr[2], x[2];
 #pragma unroll
