@@ -152,28 +152,107 @@ struct Assembler {
     return acc;
   }
 
-  // packed upper-triangular lookup of the point's G = J^T J / sigma^2
-  __device__ __forceinline__ static double Gat(const double* pt, int a, int bb) {
-    const int lo = min(a, bb), hi = max(a, bb);
-    return pt[lo * D - (lo * (lo - 1)) / 2 + (hi - lo)];
-  }
-  // (Hint_L^T G Hint_R)[kr][kc] for Hint = diag(M (3x3), s I): Pose2 interpolated obstacle factor
-  __device__ __forceinline__ static double hint_quad(const double* pt, const double* ML, double sL,
-                                                     const double* MR, double sR, int kr, int kc) {
-    double acc = 0.0;
-    const int a0 = kr < 3 ? 0 : kr, a1 = kr < 3 ? 3 : kr + 1;
-    const int b0 = kc < 3 ? 0 : kc, b1 = kc < 3 ? 3 : kc + 1;
-    for (int a = a0; a < a1; a++) {
-      const double la = kr < 3 ? ML[a * 3 + kr] : sL;
-      for (int bb = b0; bb < b1; bb++) acc = fma(la * (kc < 3 ? MR[bb * 3 + kc] : sR), Gat(pt, a, bb), acc);
-    }
-    return acc;
-  }
   // (Hint^T g)[kr]
   __device__ __forceinline__ static double hint_vec(const double* pt, const double* M, double s, int kr) {
     const double* gp_ = pt + NG;
     if (kr >= 3) return s * gp_[kr];
     return M[0 * 3 + kr] * gp_[0] + M[1 * 3 + kr] * gp_[1] + M[2 * 3 + kr] * gp_[2];
+  }
+
+  // ---- Pose2 robots: interpolated obstacle factors through the matrix cores.
+  // With Hint_k = diag(M_k (3x3), s_k I) the contribution of one interpolated point to the block rows / columns of a
+  // support state is the congruence E_L^T G E_R, E = [Hint_x | Hint_v] (D x n) of the state's role in the interval
+  // (role 0: first state -> M1, M2, Lambda scalars; role 1: second state -> M3, M4, Psi scalars).  E and G are
+  // formed in the tile layout straight from the point's LDS record (rows = configuration coordinate) and the two
+  // products run as v_mfma_f64_16x16x4 chains that accumulate over the sub-steps -- no per-entry case analysis.
+  static constexpr int KT = (D + 15) / 16;  // tiles along the contracted (configuration) dimension
+  // E tile: rows a = 16 rt + (lane >> 4) + 4 k, columns j = cbase + (lane & 15) of the state's [x; v] block
+  __device__ __forceinline__ Tile hint_tile(const double* M, const double* cf, int role, int rt, int cbase) const {
+    const int j = cbase + (lane & 15), av = j >= D, kk = j - av * D;
+    const double* Mk = M + (role * 2 + av) * 9;
+    const double sk = cf[role * 2 + av];
+    Tile T;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int a = 16 * rt + (lane >> 4) + 4 * k;
+      const bool pose = a < 3 && kk < 3;
+      const double m = Mk[pose ? a * 3 + kk : 0];
+      const double v = pose ? m : ((a == kk && a >= 3) ? sk : 0.0);
+      T.r[k] = (a < D && j < n) ? v : 0.0;
+    }
+    return T;
+  }
+  // G tile (rt, ct) of the point's packed J^T J / sigma^2
+  __device__ __forceinline__ Tile g_tile(const double* pt, int rt, int ct) const {
+    const int a2 = 16 * ct + (lane & 15);
+    Tile T;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int a = 16 * rt + (lane >> 4) + 4 * k;
+      const bool in = a < D && a2 < D;
+      const int lo = in ? min(a, a2) : 0, hi = in ? max(a, a2) : 0;
+      const double v = pt[lo * D - (lo * (lo - 1)) / 2 + (hi - lo)];
+      T.r[k] = in ? v : 0.0;
+    }
+    return T;
+  }
+  // acc += A^T B over the rows of tile row `rt` that hold configuration coordinates
+  __device__ __forceinline__ static void mfma_atb_acc(const Tile& A, const Tile& B, int rt, v4d& acc) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (16 * rt + 4 * k >= D) continue;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.r[k], B.r[k], acc, 0, 0, 0);
+    }
+  }
+  // acc += E_L^T G E_R for the output tile (row0, col0); EL[ra] = E_L tiles of the rows
+  __device__ __forceinline__ void congruence(const double* pt, const Tile (&EL)[KT], const double* M, const double* cf,
+                                             int roleR, v4d& acc) const {
+#pragma unroll
+    for (int ra = 0; ra < KT; ra++) {
+      v4d ge = {0.0, 0.0, 0.0, 0.0};   // (G E_R) rows of tile row ra
+#pragma unroll
+      for (int rb = 0; rb < KT; rb++) {
+        const Tile Gt = g_tile(pt, rb, ra);                  // G is symmetric: G[rb][ra]^T = G[ra][rb]
+        const Tile ER = hint_tile(M, cf, roleR, rb, col0);
+        mfma_atb_acc(Gt, ER, rb, ge);
+      }
+      Tile GE;
+#pragma unroll
+      for (int k = 0; k < 4; k++) GE.r[k] = ge[k];
+      mfma_atb_acc(EL[ra], GE, ra, acc);
+    }
+  }
+  __device__ __forceinline__ void lie_interp(const Slot& si, const Slot& sn, bool has_prev, bool has_next, bool want_c,
+                                             double (&dk)[4], double (&hrk)[4], double (&hlk)[4]) const {
+    v4d ad = {dk[0], dk[1], dk[2], dk[3]}, ar_ = {hrk[0], hrk[1], hrk[2], hrk[3]}, al = {hlk[0], hlk[1], hlk[2], hlk[3]};
+#pragma unroll 1
+    for (int jj = 0; jj < P.I; jj++) {
+      const double* cf = si.coef(jj) + 16;       // l11 l12 p11 p12
+      if (has_prev) {   // interval i: state i is the second state; H_{i,i-1}: columns of the first state
+        const double* pt = si.pt(jj);
+        const double* M = pt + RECP;
+        Tile EL[KT];
+#pragma unroll
+        for (int ra = 0; ra < KT; ra++) EL[ra] = hint_tile(M, cf, 1, ra, row0);
+        congruence(pt, EL, M, cf, 1, ad);
+        if (want_c) congruence(pt, EL, M, cf, 0, al);
+      }
+      if (has_next) {   // interval i + 1: state i is the first state; H_{i,i+1}: columns of the second state
+        const double* pt = sn.pt(jj);
+        const double* M = pt + RECP;
+        Tile EL[KT];
+#pragma unroll
+        for (int ra = 0; ra < KT; ra++) EL[ra] = hint_tile(M, cf, 0, ra, row0);
+        congruence(pt, EL, M, cf, 0, ad);
+        if (want_c) congruence(pt, EL, M, cf, 1, ar_);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      dk[k] = ad[k];
+      hrk[k] = ar_[k];
+      hlk[k] = al[k];
+    }
   }
 
   // Tiles of block i: S = [D_i | -g_i in column RHSCOL], Cl = H_{i,i-1}, Cr = H_{i,i+1}; returns this
@@ -376,17 +455,9 @@ struct Assembler {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (!valid[k]) continue;
-      const int ar = a_row[k], kr = k_row[k], rho = g + 4 * k;
+      const int ar = a_row[k], kr = k_row[k];
       double d = 0.0, hr = 0.0, hl = 0.0;
-      if (!lie) {
-        // constant GP prior blocks: KB = Q^-1 (state i second), KA = Phi^T Q^-1 Phi (state i first),
-        // KO = -Phi^T Q^-1 = H_{i,i+1}
-        d = (has_prev ? P.KB[rho * n + c] : 0.0) + (has_next ? P.KA[rho * n + c] : 0.0);
-        if (want_c) {
-          hr = has_next ? P.KO[rho * n + c] : 0.0;
-          hl = has_prev ? P.KO[c * n + rho] : 0.0;
-        }
-      } else {
+      {
         // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
         const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
         if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
@@ -405,46 +476,9 @@ struct Assembler {
       hrk[k] = hr;
       hlk[k] = hl;
     }
-    // interpolated obstacle factors: interval i (state i second) and interval i+1 (state i first)
-#pragma unroll 1
-    for (int jj = 0; jj < I; jj++) {
-      const double* cf = si.coef(jj) + 16;       // l11 l12 p11 p12 (broadcast LDS reads)
-      const double w1c = ac ? cf[1] : cf[0], w2c = ac ? cf[3] : cf[2];
-      const double w1x = cf[0], w1v = cf[1], w2x = cf[2], w2v = cf[3];
-      const double* pp_ = si.pt(jj);
-      const double* pn_ = sn.pt(jj);
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        if (!valid[k]) continue;
-        const int ar = a_row[k], kr = k_row[k];
-        const double w1r = ar ? w1v : w1x, w2r = ar ? w2v : w2x;
-        if (lie) {
-          // Hint_k = diag(M_k, s_k I), k = (x_first, v_first, x_second, v_second)
-          if (has_prev) {
-            const double* M = pp_ + RECP;
-            dk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 27 : 18), w2c, kr, kc);
-            if (want_c) hlk[k] += hint_quad(pp_, M + (ar ? 27 : 18), w2r, M + (ac ? 9 : 0), w1c, kr, kc);
-          }
-          if (has_next) {
-            const double* M = pn_ + RECP;
-            dk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 9 : 0), w1c, kr, kc);
-            if (want_c) hrk[k] += hint_quad(pn_, M + (ar ? 9 : 0), w1r, M + (ac ? 27 : 18), w2c, kr, kc);
-          }
-          continue;
-        }
-        const int t = tri[k];
-        if (has_prev) {
-          const double Gp = pp_[t];
-          dk[k] = fma(w2r * w2c, Gp, dk[k]);
-          if (want_c) hlk[k] = fma(w2r * w1c, Gp, hlk[k]);  // rows: state i (second), cols: state i-1 (first)
-        }
-        if (has_next) {
-          const double Gn = pn_[t];
-          dk[k] = fma(w1r * w1c, Gn, dk[k]);
-          if (want_c) hrk[k] = fma(w1r * w2c, Gn, hrk[k]);  // rows: state i (first), cols: state i+1 (second)
-        }
-      }
-    }
+    // interpolated obstacle factors of interval i (state i is the second state) and interval i + 1 (first state):
+    // congruences E_L^T G E_R on the matrix cores, see lie_interp
+    lie_interp(si, sn, has_prev, has_next, want_c, dk, hrk, hlk);
     }
     G2_BSTAMP(3);
     for (int e = 0; e < nxp; e++) {

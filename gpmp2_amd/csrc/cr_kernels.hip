@@ -193,7 +193,7 @@ constexpr int ASM_WAVES = 4;
 #define G2_ASM_MINW 5
 #endif
 template <int D, bool LIE>
-__global__ __launch_bounds__(64 * ASM_WAVES, G2_ASM_MINW) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
+__global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assemble(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                               const double* __restrict__ traj, int bufsel,
                                                               double* __restrict__ tiles,
                                                               const int* __restrict__ active) {

@@ -212,7 +212,7 @@ __device__ __forceinline__ void wcr_backsolve(const WTile& Wl, const WTile& Wr, 
 
 // =============================================================================== assemble (wide)
 template <int D, bool LIE>
-__global__ __launch_bounds__(64) void k_assemble_wide(const PlanParams* __restrict__ pp, PlanBuffers pb,
+__global__ __launch_bounds__(64, 2) void k_assemble_wide(const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                        const double* __restrict__ traj, int bufsel,
                                                        const int* __restrict__ active) {
   constexpr int n = 2 * D;

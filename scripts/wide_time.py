@@ -1,5 +1,6 @@
 """Throughput of the dense (8 <= dof <= 11) path: Pose2 mobile base + 7-joint WAM arm (dof 10), N = 100, I = 5,
 Synth200 field scaled to the robot, LM and GN, against the same problem on the CPU oracle."""
+import os
 import sys
 import time
 
@@ -22,7 +23,7 @@ D, N, B = 10, 100, 64
 for opt in ("GN", "LM"):
     st = TrajOptimizerSetting(D)
     st.set_total_step(N); st.set_total_time(10.0); st.set_obs_check_inter(5); st.set_cost_sigma(0.05); st.set_epsilon(0.3)
-    st.set_conf_prior_model(1e-3); st.set_vel_prior_model(1e-3); st.set_Qc_model(np.eye(D)); st.set_max_iter(50)
+    st.set_conf_prior_model(1e-3); st.set_vel_prior_model(1e-3); st.set_Qc_model(np.eye(D)); st.set_max_iter(int(os.environ.get('WIDE_MAX_ITER', '50')))
     {"GN": st.setGaussNewton, "LM": st.setLM}[opt]()
     start = np.concatenate([[-2.0, -1.5, 0.0], problems.WAM_START])
     end = np.concatenate([[2.0, 1.5, 0.5], problems.WAM_END])
@@ -46,6 +47,8 @@ for opt in ("GN", "LM"):
     res = pl.result()
     print(opt, f"GPU {B / dt:.0f} traj/s ({dt * 1e3:.1f} ms per batch of {B}); iters {res['iters'].min()}..{res['iters'].max()}",
           {k: round(v['ms'] / v['launches'] * 1e3, 1) for k, v in pl.timing().items()}, flush=True)
+    if os.environ.get('WIDE_NO_ORACLE'):
+        continue
     ro, so = orc.robot(model), orc.sdf(origin, cell, data)
     t0 = time.perf_counter()
     ref = orc.batch_optimize(ro, so, st, *args, init, nthreads=64)
