@@ -874,7 +874,17 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.Npad = (P.N + 1 + 63) / 64 * 64;
   P.lie = robot->h.base_dof == 3 ? 1 : 0;
   P.wide = wide ? 1 : 0;
-  P.split_back = (P.N >= 8 && !wide) ? 1 : 0;
+  const char* wd_env = getenv("GPMP2MI_WIDE_DENSE");
+  const bool dense_path = dense_only || (wide && wd_env && wd_env[0] == '1');   // dense block solver: no split tail
+  P.split_back = (dense_path ? false : wide ? P.N >= 16 : P.N >= 8) ? 1 : 0;
+  P.spart_groups = wide ? (P.N + 8) / 8 : (P.N + 4) / 4;
+  // wide blocks: the first forward levels (2, 4) run chip-wide when they are not among the last two of the tree
+  P.wide_h0 = 2;
+  if (wide) {
+    const char* e = getenv("GPMP2MI_WIDE_H0");
+    const int want = e ? atoi(e) : 8;   // (16 measured: see DESIGN)
+    while (P.wide_h0 < want && 4 * P.wide_h0 <= P.N) P.wide_h0 *= 2;
+  }
   P.GPREC = P.n + 1 + (P.lie ? 18 : 0);
   P.RECS = (P.REC + 1) & ~1;
   P.GPS = (P.GPREC + 1) & ~1;
@@ -977,7 +987,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
   G2_TRY(plan_alloc(p.get(), &pb.spart, (size_t)B * ((P.N + 4) / 4) * 3));
-  G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * 16));
+  G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * (wide ? 32 : 16)));
   if (wide) {
     G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
     G2_TRY(plan_alloc(p.get(), &pb.wHo, (size_t)B * P.N * P.n * P.n));
@@ -1230,8 +1240,16 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
           p->timer.begin("ghg_wide", st);
           G2_TRY(launch_ghg_wide(P, pb, st));
         }
+        for (int h = 2; h < P.wide_h0; h *= 2) {
+          p->timer.begin(h == 2 ? "cr_level2_wide" : "cr_level4_wide", st);
+          G2_TRY(launch_cr_level_wide(P, pb, h, st));
+        }
         p->timer.begin("solve_step_wide", st);
         G2_TRY(launch_solve_step_wide(P, pb, st));
+        if (P.split_back && P.opt_type != GPMP2MI_OPT_DOGLEG) {   // LM / GN: levels 4, 2, 1, step and trial point chip-wide
+          p->timer.begin("finish_trial_wide", st);
+          G2_TRY(launch_finish_trial_wide(P, pb, st));
+        }
       } else {
         p->timer.begin("assemble", st);
         G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));

@@ -204,48 +204,48 @@ struct Assembler {
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.r[k], B.r[k], acc, 0, 0, 0);
     }
   }
-  // acc += E_L^T G E_R for the output tile (row0, col0); EL[ra] = E_L tiles of the rows
-  __device__ __forceinline__ void congruence(const double* pt, const Tile (&EL)[KT], const double* M, const double* cf,
-                                             int roleR, v4d& acc) const {
+  // acc += E_L^T G E_R for one output tile; G[rb][ra], EL[ra], ER[rb] = tiles along the configuration dimension
+  __device__ __forceinline__ static void congruence(const Tile (&G)[KT][KT], const Tile (&EL)[KT], const Tile (&ER)[KT],
+                                                    v4d& acc) {
 #pragma unroll
     for (int ra = 0; ra < KT; ra++) {
-      v4d ge = {0.0, 0.0, 0.0, 0.0};   // (G E_R) rows of tile row ra
+      v4d ge = {0.0, 0.0, 0.0, 0.0};   // (G E_R) rows of tile row ra; G is symmetric: G[rb][ra]^T = G[ra][rb]
 #pragma unroll
-      for (int rb = 0; rb < KT; rb++) {
-        const Tile Gt = g_tile(pt, rb, ra);                  // G is symmetric: G[rb][ra]^T = G[ra][rb]
-        const Tile ER = hint_tile(M, cf, roleR, rb, col0);
-        mfma_atb_acc(Gt, ER, rb, ge);
-      }
+      for (int rb = 0; rb < KT; rb++) mfma_atb_acc(G[rb][ra], ER[rb], rb, ge);
       Tile GE;
 #pragma unroll
       for (int k = 0; k < 4; k++) GE.r[k] = ge[k];
       mfma_atb_acc(EL[ra], GE, ra, acc);
     }
   }
+  bool skip_interp = false;   // kernels that add the interpolated factors of all tiles of a wide block in one go
   __device__ __forceinline__ void lie_interp(const Slot& si, const Slot& sn, bool has_prev, bool has_next, bool want_c,
                                              double (&dk)[4], double (&hrk)[4], double (&hlk)[4]) const {
+    if (skip_interp) return;
     v4d ad = {dk[0], dk[1], dk[2], dk[3]}, ar_ = {hrk[0], hrk[1], hrk[2], hrk[3]}, al = {hlk[0], hlk[1], hlk[2], hlk[3]};
+    // one interpolated point: rows take the role of state i in the interval, the coupling's columns the other role
+    auto point = [&](const double* pt, const double* cf, int role, v4d& acc_d, v4d& acc_c) {
+      const double* M = pt + RECP;
+      Tile G[KT][KT], EL[KT], ER[KT];
+#pragma unroll
+      for (int ra = 0; ra < KT; ra++) {
+#pragma unroll
+        for (int rb = 0; rb < KT; rb++) G[rb][ra] = g_tile(pt, rb, ra);
+        EL[ra] = hint_tile(M, cf, role, ra, row0);
+        ER[ra] = hint_tile(M, cf, role, ra, col0);
+      }
+      congruence(G, EL, ER, acc_d);
+      if (want_c) {
+#pragma unroll
+        for (int ra = 0; ra < KT; ra++) ER[ra] = hint_tile(M, cf, 1 - role, ra, col0);
+        congruence(G, EL, ER, acc_c);
+      }
+    };
 #pragma unroll 1
     for (int jj = 0; jj < P.I; jj++) {
       const double* cf = si.coef(jj) + 16;       // l11 l12 p11 p12
-      if (has_prev) {   // interval i: state i is the second state; H_{i,i-1}: columns of the first state
-        const double* pt = si.pt(jj);
-        const double* M = pt + RECP;
-        Tile EL[KT];
-#pragma unroll
-        for (int ra = 0; ra < KT; ra++) EL[ra] = hint_tile(M, cf, 1, ra, row0);
-        congruence(pt, EL, M, cf, 1, ad);
-        if (want_c) congruence(pt, EL, M, cf, 0, al);
-      }
-      if (has_next) {   // interval i + 1: state i is the first state; H_{i,i+1}: columns of the second state
-        const double* pt = sn.pt(jj);
-        const double* M = pt + RECP;
-        Tile EL[KT];
-#pragma unroll
-        for (int ra = 0; ra < KT; ra++) EL[ra] = hint_tile(M, cf, 0, ra, row0);
-        congruence(pt, EL, M, cf, 0, ad);
-        if (want_c) congruence(pt, EL, M, cf, 1, ar_);
-      }
+      if (has_prev) point(si.pt(jj), cf, 1, ad, al);   // interval i: state i second; H_{i,i-1}: columns of the first state
+      if (has_next) point(sn.pt(jj), cf, 0, ad, ar_);  // interval i + 1: state i first; H_{i,i+1}: columns of the second
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {

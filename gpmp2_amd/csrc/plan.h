@@ -20,6 +20,8 @@ struct PlanParams {
   int end_conf_prior_off;              // 1: no PriorFactor on x_N (a goal / workspace factor stands in)
   int wide;                            // 2 dof > 15: dense block path (k_export_normal_eq + k_solve_dense)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
+  int spart_groups;                    // workgroups per trajectory of k_finish_trial(_wide)
+  int wide_h0;                         // wide blocks: first forward level k_solve_step_wide runs itself (levels below: k_cr_level_wide)
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
   double conf_prior_w, vel_prior_w;    // 1 / sigma^2
   double vdyn_w;                       // 1 / dynamics_sigma^2 or 0
@@ -97,7 +99,7 @@ struct PlanBuffers {
   double* wHd;             // [B][N+1][n][n]   diagonal blocks, then their upper Cholesky factors R_i
   double* wHo;             // [B][N][n][n]     block (i+1, i), then W_i = R_i^-T H_{i,i+1}
   double* wg;              // [B][N+1][n]      gradient, then y_i
-  double* xg;              // [B][N+1][16] step of the blocks the solve kernel back-substitutes itself (split path)
+  double* xg;              // [B][N+1][16 or 32] step of the blocks the solve kernel back-substitutes itself (split path)
   int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path); trial-step
                            // path: 1 when k_solve_step left a factorisation for k_finish_trial
   double* spart;           // [B][ceil((N+1)/4)][3] per-group shares of g.delta, |delta|^2, |g|^2 (k_finish_trial)
@@ -154,6 +156,8 @@ int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const doub
                          const int* active, hipStream_t st);
 int launch_ghg_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_solve_step_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_finish_trial_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_cr_level_wide(const PlanParams& hp, const PlanBuffers& pb, int h, hipStream_t st);
 int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                         double* err, hipStream_t st);
 int launch_export_normal_eq(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,

@@ -438,7 +438,7 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
     // LM / GN split form: g.delta, |delta|^2, |g|^2 arrive as per-group shares of k_finish_trial (fixed-order wave sums)
     double sp_gd = 0.0, sp_dd = 0.0, sp_gg = 0.0;
     if (P.split_back && P.opt_type == GPMP2MI_OPT_LM && !failed) {
-      const int groups = (N + 4) / 4;
+      const int groups = P.spart_groups;
       const double* sp = pb.spart + (size_t)b * groups * 3;
       for (int qq = lane; qq < groups; qq += 64) {
         sp_gd += sp[3 * qq];

@@ -210,6 +210,66 @@ __device__ __forceinline__ void wcr_backsolve(const WTile& Wl, const WTile& Wr, 
   }
 }
 
+// Interpolated obstacle factors of a Pose2 robot for all four tiles of a wide block at once (the one-tile form
+// Assembler::lie_interp would rebuild G and the E tiles for every output tile): per point one G tile (dof <= 16),
+// the E tiles of both column halves, G E once per half, then the 2 x 2 outer products E_L^T (G E_R).
+template <int D, bool LIE>
+__device__ __forceinline__ void wide_lie_interp(const Assembler<D, LIE>& as, const typename Assembler<D, LIE>::Slot& si,
+                                                const typename Assembler<D, LIE>::Slot& sn, bool has_prev, bool has_next,
+                                                bool want_c, WTile& S, WTile& Cl, WTile& Cr) {
+  using Asm = Assembler<D, LIE>;
+  static_assert(D <= 16, "one tile along the configuration dimension");
+  v4d aS[2][2], aL[2][2], aR[2][2];
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      aS[q >> 1][q & 1][k] = S.t[q >> 1][q & 1].r[k];
+      aL[q >> 1][q & 1][k] = Cl.t[q >> 1][q & 1].r[k];
+      aR[q >> 1][q & 1][k] = Cr.t[q >> 1][q & 1].r[k];
+    }
+  auto ge_of = [&](const Tile& G, const Tile& E) {
+    v4d ge = {0.0, 0.0, 0.0, 0.0};
+    Asm::mfma_atb_acc(G, E, 0, ge);
+    Tile T;
+#pragma unroll
+    for (int k = 0; k < 4; k++) T.r[k] = ge[k];
+    return T;
+  };
+  auto point = [&](const double* pt, const double* cf, int role, v4d (&accD)[2][2], v4d (&accC)[2][2]) {
+    const double* M = pt + Asm::RECP;
+    const Tile G = as.g_tile(pt, 0, 0);
+    Tile Er[2], GE[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      Er[h] = as.hint_tile(M, cf, role, 0, 16 * h);
+      GE[h] = ge_of(G, Er[h]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) Asm::mfma_atb_acc(Er[q >> 1], GE[q & 1], 0, accD[q >> 1][q & 1]);
+    if (want_c) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) GE[h] = ge_of(G, as.hint_tile(M, cf, 1 - role, 0, 16 * h));
+#pragma unroll
+      for (int q = 0; q < 4; q++) Asm::mfma_atb_acc(Er[q >> 1], GE[q & 1], 0, accC[q >> 1][q & 1]);
+    }
+  };
+#pragma unroll 1
+  for (int jj = 0; jj < as.P.I; jj++) {
+    const double* cf = si.coef(jj) + 16;
+    if (has_prev) point(si.pt(jj), cf, 1, aS, aL);
+    if (has_next) point(sn.pt(jj), cf, 0, aS, aR);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      S.t[q >> 1][q & 1].r[k] = aS[q >> 1][q & 1][k];
+      Cl.t[q >> 1][q & 1].r[k] = aL[q >> 1][q & 1][k];
+      Cr.t[q >> 1][q & 1].r[k] = aR[q >> 1][q & 1][k];
+    }
+}
+
 // =============================================================================== assemble (wide)
 template <int D, bool LIE>
 __global__ __launch_bounds__(64, 2) void k_assemble_wide(const PlanParams* __restrict__ pp, PlanBuffers pb,
@@ -237,8 +297,10 @@ __global__ __launch_bounds__(64, 2) void k_assemble_wide(const PlanParams* __res
   static_for<0, 4>([&](auto qc) {  // forced unrolling: the four tiles must stay in registers
     constexpr int ti = decltype(qc)::value >> 1, tj = decltype(qc)::value & 1;
     Asm at(P, pb, rec, gpu, b, lane, 16 * ti, 16 * tj, WRHS);
+    at.skip_interp = LIE;
     at.build_tiles(i, slot0, slot1, zi, S.t[ti][tj], Cl.t[ti][tj], Cr.t[ti][tj], want_c);
   });
+  if constexpr (LIE) wide_lie_interp<D, LIE>(as, slot0, slot1, i > 0, i < N, want_c, S, Cl, Cr);
   // gradient g_i (the rhs column holds -g_i)
   if (c == 15) {
 #pragma unroll
@@ -341,64 +403,103 @@ int launch_ghg_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st)
 // =============================================================================== solve step (wide)
 constexpr int WCR_WAVES = 8;  // 16 tiles of state per elimination: 2 wavefronts per SIMD keep 256 VGPRs each
 
+// One task of forward level h: idx < countE eliminates the idx-th odd multiple of h (E task), the others bring the
+// diagonal block of an even multiple up to date (U task).
 template <int n>
-__device__ __forceinline__ bool wcr_forward(const PlanBuffers& pb, int b, int N, int tid) {
-  const int w = tid >> 6, lane = tid & 63;
+__device__ __forceinline__ bool wcr_task(const PlanBuffers& pb, int b, int N, int h, int idx, int countE, bool final,
+                                         int lane) {
   double* tiles = pb.tiles + (size_t)b * (N + 1) * WTILE_DBL;
   double* fac = pb.fac + (size_t)b * (N + 1) * 3 * WTILE_DBL;
+  const int hh = h >> 1;
+  const bool elim = idx < countE;
+  const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
+  WTile S = wtile_load_rows<n>(tiles + (size_t)j * WTILE_DBL, lane);
+  WTile Cl = wtile_zero(), Cr = wtile_zero();
+  const int jm = j - hh, jp = j + hh;
+  if (jm >= 0) {
+    const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jm * 3 + 1) * WTILE_DBL, lane);
+    wschur_sub<n>(S, Wr, lane);
+    if (elim && !final) {
+      const WTile Wl = wtile_load_rows<n>(fac + (size_t)jm * 3 * WTILE_DBL, lane);
+      Cl = wcoupling<n>(Wr, Wl, lane);  // rows j, cols j - h
+    }
+  }
+  if (jp <= N) {
+    const WTile Wl = wtile_load_rows<n>(fac + (size_t)jp * 3 * WTILE_DBL, lane);
+    wschur_sub<n>(S, Wl, lane);
+    if (elim && !final && j + h <= N) {
+      const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jp * 3 + 1) * WTILE_DBL, lane);
+      Cr = wcoupling<n>(Wl, Wr, lane);  // rows j, cols j + h
+    }
+  }
+  if (!elim) {
+    wtile_store_rows<n>(tiles + (size_t)j * WTILE_DBL, S, lane);
+    return true;
+  }
+  WTile V = wtile_identity(lane);
+  const bool ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane);
+  double* f = fac + (size_t)j * 3 * WTILE_DBL;
+  wtile_store_rows<n>(f, Cl, lane);
+  wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
+  wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
+  return ok;
+}
+
+// levels h0 .. of the reduction inside the trajectory's workgroup (levels below h0 ran chip-wide, k_cr_level_wide)
+template <int n>
+__device__ __forceinline__ bool wcr_forward(const PlanBuffers& pb, int b, int N, int tid, int h0) {
+  const int w = tid >> 6, lane = tid & 63;
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  for (int h = 2; h <= hfinal; h <<= 1) {
+  for (int h = h0; h <= hfinal; h <<= 1) {
     const bool final = (h == hfinal);
-    const int hh = h >> 1;
     const int countE = final ? 1 : ((N / h) + 1) / 2;
     const int countU = final ? 0 : (N / (2 * h)) + 1;
-    for (int idx = w; idx < countE + countU; idx += WCR_WAVES) {
-      const bool elim = idx < countE;
-      const int j = elim ? (final ? 0 : h * (2 * idx + 1)) : 2 * h * (idx - countE);
-      WTile S = wtile_load_rows<n>(tiles + (size_t)j * WTILE_DBL, lane);
-      WTile Cl = wtile_zero(), Cr = wtile_zero();
-      const int jm = j - hh, jp = j + hh;
-      if (jm >= 0) {
-        const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jm * 3 + 1) * WTILE_DBL, lane);
-        wschur_sub<n>(S, Wr, lane);
-        if (elim && !final) {
-          const WTile Wl = wtile_load_rows<n>(fac + (size_t)jm * 3 * WTILE_DBL, lane);
-          Cl = wcoupling<n>(Wr, Wl, lane);  // rows j, cols j - h
-        }
-      }
-      if (jp <= N) {
-        const WTile Wl = wtile_load_rows<n>(fac + (size_t)jp * 3 * WTILE_DBL, lane);
-        wschur_sub<n>(S, Wl, lane);
-        if (elim && !final && j + h <= N) {
-          const WTile Wr = wtile_load_rows<n>(fac + ((size_t)jp * 3 + 1) * WTILE_DBL, lane);
-          Cr = wcoupling<n>(Wl, Wr, lane);  // rows j, cols j + h
-        }
-      }
-      if (!elim) {
-        wtile_store_rows<n>(tiles + (size_t)j * WTILE_DBL, S, lane);
-        continue;
-      }
-      WTile V = wtile_identity(lane);
-      ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
-      double* f = fac + (size_t)j * 3 * WTILE_DBL;
-      wtile_store_rows<n>(f, Cl, lane);
-      wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
-      wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
-    }
+    for (int idx = w; idx < countE + countU; idx += WCR_WAVES) ok = wcr_task<n>(pb, b, N, h, idx, countE, final, lane) && ok;
     __syncthreads();
   }
   return ok;
 }
 
+// One forward level (never the final one) spread over the chip: one wavefront per task.  The first levels of a
+// 100-state trajectory are 51 and 26 tasks -- 7 and 4 rounds of the 8 wavefronts of k_solve_step_wide.
+template <int D>
+__global__ __launch_bounds__(64, 2) void k_cr_level_wide(const PlanParams* __restrict__ pp, PlanBuffers pb, int h) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int countE = ((N / h) + 1) / 2, countU = (N / (2 * h)) + 1, per = countE + countU;
+  const int b = blockIdx.x / per, idx = blockIdx.x - b * per;
+  if (!pb.active[b]) return;
+  if (P.opt_type == GPMP2MI_OPT_DOGLEG && pb.phase[b] != 0) return;
+  const bool ok = wcr_task<n>(pb, b, N, h, idx, countE, false, threadIdx.x);
+  if (!ok && threadIdx.x == 0) pb.notspd[b] = 1;
+}
+
+int launch_cr_level_wide(const PlanParams& hp, const PlanBuffers& pb, int h, hipStream_t st) {
+  const int countE = ((hp.N / h) + 1) / 2, countU = (hp.N / (2 * h)) + 1;
+  const dim3 grid(hp.B * (countE + countU)), block(64);
+  switch (hp.D) {
+#define G2_CRLW_CASE(DD) \
+  case DD: k_cr_level_wide<DD><<<grid, block, 0, st>>>(pb.params, pb, h); break;
+    G2_CRLW_CASE(8) G2_CRLW_CASE(9) G2_CRLW_CASE(10) G2_CRLW_CASE(11)
+#undef G2_CRLW_CASE
+    default:
+      set_error("wide blocks are instantiated for 8 <= dof <= 11");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 template <int n>
-__device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs) {
+__device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs, int hmin = 1) {
   const int w = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * WTILE_DBL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  for (int h = hfinal; h >= 1; h >>= 1) {
+  for (int h = hfinal; h >= hmin; h >>= 1) {
     const bool final = (h == hfinal);
     const int count = final ? 1 : ((N / h) + 1) / 2;
     for (int idx = w; idx < count; idx += WCR_WAVES) {
@@ -452,14 +553,29 @@ __global__ __launch_bounds__(64 * WCR_WAVES) void k_solve_step_wide(const PlanPa
   int* flags = reinterpret_cast<int*>(red + WCR_WAVES);
   const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
   const bool resolve = !(dogleg && pb.phase[b] != 0);
-  if (tid == 0) flags[1] = 0;
+  if (tid == 0) {
+    flags[1] = 0;
+    pb.stepped[b] = 0;   // set again once the factorisation has succeeded (split form)
+  }
   __syncthreads();
   if (resolve) {
-    const bool ok = wcr_forward<n>(pb, b, N, tid);
+    const bool ok = wcr_forward<n>(pb, b, N, tid, P.wide_h0);
     if ((!ok && (tid & 63) == 0) || (tid == 0 && pb.notspd[b])) flags[1] = 1;
     __syncthreads();
     if (flags[1]) {
       if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
+      return;
+    }
+    if (P.split_back && !dogleg) {
+      // LM / GN: only the blocks that are multiples of 8 are back-substituted here; levels 4, 2, 1, the step, the
+      // trial point and the step-control sums follow chip-wide in k_finish_trial_wide
+      wcr_backward<n>(pb, b, N, tid, xs, 8);
+      double* xg = pb.xg + (size_t)b * (N + 1) * WX;
+      for (int k = tid; k < (N / 8 + 1) * WX; k += blockDim.x) {
+        const size_t o = (size_t)(k / WX) * 8 * WX + (k % WX);
+        xg[o] = xs[o];
+      }
+      if (tid == 0) pb.stepped[b] = 1;
       return;
     }
     wcr_backward<n>(pb, b, N, tid, xs);
@@ -544,6 +660,98 @@ __global__ __launch_bounds__(64 * WCR_WAVES) void k_solve_step_wide(const PlanPa
     sc[SC_Q] = q;
     sc[SC_XNORM] = sqrt(xn);
   }
+}
+
+// Chip-wide tail of an LM / GN trial step for wide blocks: one workgroup of 8 wavefronts per (trajectory, blocks
+// 8q .. 8q+7).  Block 8q+4 is back-substituted from x_{8q}, x_{8q+8} (level 4), then 8q+2 / 8q+6 (level 2), then the odd
+// blocks (level 1); every wavefront then writes the step and the trial point cur (+) delta of its own state and the
+// workgroup leaves its share of g.delta, |delta|^2, |g|^2 in spart (k_decide sums them in group order).
+template <int D>
+__global__ __launch_bounds__(512) void k_finish_trial_wide(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+  constexpr int n = 2 * D;
+  const PlanParams& P = *pp;
+  const int N = P.N;
+  const int groups = (N + 8) / 8;
+  const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
+  if (!pb.active[b] || pb.stepped[b] != 1) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int i = 8 * q + wv;
+  const bool live = i <= N;
+  __shared__ double xl_[9][WX];
+  __shared__ double psum[8][3];
+  const double* xg = pb.xg + (size_t)b * (N + 1) * WX;
+  const double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * WTILE_DBL;
+  const bool has_block = live && wv != 0;
+  WTile Wl = wtile_zero(), Wr = wtile_zero(), V = wtile_zero();
+  if (has_block) {
+    Wl = wtile_load_rows<n>(f, lane);
+    Wr = wtile_load_rows<n>(f + WTILE_DBL, lane);
+    V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
+  }
+  if (wv == 0 && lane < WX) xl_[0][lane] = xg[(size_t)(8 * q) * WX + lane];
+  if (wv == 1 && lane < WX) xl_[8][lane] = (8 * q + 8 <= N) ? xg[(size_t)(8 * q + 8) * WX + lane] : 0.0;
+  __syncthreads();
+  auto solve = [&](int h) {
+    const int jl = i - h, jr = i + h;
+    double xl[2], xr[2], x[2];
+#pragma unroll
+    for (int tc = 0; tc < 2; tc++) {
+      xl[tc] = (jl >= 0) ? xl_[jl - 8 * q][16 * tc + c] : 0.0;
+      xr[tc] = (jr <= N) ? xl_[jr - 8 * q][16 * tc + c] : 0.0;
+    }
+    wcr_backsolve<n>(Wl, Wr, V, xl, xr, lane, x);
+    if (g == 0) {
+#pragma unroll
+      for (int tc = 0; tc < 2; tc++) xl_[wv][16 * tc + c] = (16 * tc + c < n) ? x[tc] : 0.0;
+    }
+  };
+  if (wv == 4 && live) solve(4);
+  __syncthreads();
+  if ((wv == 2 || wv == 6) && live) solve(2);
+  __syncthreads();
+  if ((wv & 1) && live) solve(1);
+  __syncthreads();
+  double gd = 0.0, dd = 0.0, gg = 0.0;
+  if (live && lane < n) {
+    const size_t k = ((size_t)b * (N + 1) + i) * n + lane;
+    const double* zs = pb.cur + ((size_t)b * (N + 1) + i) * n;
+    const double x = xl_[wv][lane], gk = pb.gvec[((size_t)b * (N + 1) + i) * WX + lane];
+    pb.delta[k] = x;
+    pb.trial[k] = (lane < D) ? retract_coord(P.lie != 0, lane, zs, xl_[wv]) : zs[lane] + x;
+    gd = gk * x;
+    dd = x * x;
+    gg = gk * gk;
+  }
+  gd = wave_sum(gd);
+  dd = wave_sum(dd);
+  gg = wave_sum(gg);
+  if (lane == 0) {
+    psum[wv][0] = gd;
+    psum[wv][1] = dd;
+    psum[wv][2] = gg;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int t = threadIdx.x;
+    double a = 0.0;
+    for (int w = 0; w < 8; w++) a += psum[w][t];
+    pb.spart[((size_t)b * groups + q) * 3 + t] = a;
+  }
+}
+
+int launch_finish_trial_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+  const dim3 grid(hp.B * ((hp.N + 8) / 8)), block(512);
+  switch (hp.D) {
+#define G2_FTW_CASE(DD) \
+  case DD: k_finish_trial_wide<DD><<<grid, block, 0, st>>>(pb.params, pb); break;
+    G2_FTW_CASE(8) G2_FTW_CASE(9) G2_FTW_CASE(10) G2_FTW_CASE(11)
+#undef G2_FTW_CASE
+    default:
+      set_error("wide blocks are instantiated for 8 <= dof <= 11");
+      return GPMP2MI_ERR_UNSUPPORTED;
+  }
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
 }
 
 int launch_solve_step_wide(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
