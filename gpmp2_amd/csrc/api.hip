@@ -992,6 +992,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
     G2_TRY(plan_alloc(p.get(), &pb.wHo, (size_t)B * P.N * P.n * P.n));
     G2_TRY(plan_alloc(p.get(), &pb.wg, (size_t)B * (P.N + 1) * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wWl, (size_t)B * (P.N + 1) * P.n * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wWr, (size_t)B * (P.N + 1) * P.n * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wy, (size_t)B * (P.N + 1) * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wrb, (size_t)B * (P.N + 1) * P.n));
+    G2_TRY(plan_alloc(p.get(), &pb.wx, (size_t)B * (P.N + 1) * P.n));
   }
   G2_TRY(plan_alloc(p.get(), &pb.xp_n, B));
   G2_TRY(plan_alloc(p.get(), &pb.xp_state, (size_t)B * XP_MAX));
@@ -1231,7 +1236,8 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
         p->timer.begin("export_dense", st);
         G2_TRY(launch_export_normal_eq(P, pb, pb.cur, 0, pb.wHd, pb.wHo, pb.wg, st, pb.active));
         p->timer.begin("solve_dense", st);
-        G2_TRY(launch_solve_dense(P, pb, st));
+        static const bool dense_seq = [] { const char* e = getenv("GPMP2MI_DENSE_SEQ"); return e && e[0] == '1'; }();
+        G2_TRY(dense_seq ? launch_solve_dense(P, pb, st) : launch_solve_dense_cr(P, pb, st));
       } else if (P.wide) {
         // blocks wider than one tile (8 <= dof <= 11): the same cyclic reduction on 2x2 tiles
         p->timer.begin("assemble_wide", st);

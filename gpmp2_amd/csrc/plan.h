@@ -99,6 +99,11 @@ struct PlanBuffers {
   double* wHd;             // [B][N+1][n][n]   diagonal blocks, then their upper Cholesky factors R_i
   double* wHo;             // [B][N][n][n]     block (i+1, i), then W_i = R_i^-T H_{i,i+1}
   double* wg;              // [B][N+1][n]      gradient, then y_i
+  double* wWl;             // [B][N+1][n][n]   dense cyclic reduction: W_l = R^-T C_l of every eliminated block
+  double* wWr;             // [B][N+1][n][n]   ... W_r
+  double* wy;              // [B][N+1][n]      ... y = R^-T b
+  double* wrb;             // [B][N+1][n]      ... running right-hand side of the blocks still in the tree
+  double* wx;              // [B][N+1][n]      ... solution
   double* xg;              // [B][N+1][16 or 32] step of the blocks the solve kernel back-substitutes itself (split path)
   int* stepped;            // [B] pass + 1 of the last pass in which the trajectory took a step (split path); trial-step
                            // path: 1 when k_solve_step left a factorisation for k_finish_trial
@@ -151,6 +156,7 @@ int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hip
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_trial(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
+int launch_solve_dense_cr(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 // wide_cr.h (8 <= dof <= 11 on 2x2 tiles)
 int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                          const int* active, hipStream_t st);
