@@ -1236,8 +1236,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
         p->timer.begin("export_dense", st);
         G2_TRY(launch_export_normal_eq(P, pb, pb.cur, 0, pb.wHd, pb.wHo, pb.wg, st, pb.active));
         p->timer.begin("solve_dense", st);
-        static const bool dense_seq = [] { const char* e = getenv("GPMP2MI_DENSE_SEQ"); return e && e[0] == '1'; }();
-        G2_TRY(dense_seq ? launch_solve_dense(P, pb, st) : launch_solve_dense_cr(P, pb, st));
+        G2_TRY(launch_solve_dense(P, pb, st));
       } else if (P.wide) {
         // blocks wider than one tile (8 <= dof <= 11): the same cyclic reduction on 2x2 tiles
         p->timer.begin("assemble_wide", st);

@@ -1,13 +1,11 @@
-// dense_kernels.hip -- solve step for robots whose blocks do not fit one 16x16 tile (8 <= dof <= 11).
+// dense_kernels.hip -- solve step for robots whose blocks do not fit the tile kernels (12 <= dof <= 18, the PR2
+// model; also 8 <= dof <= 11 with GPMP2MI_WIDE_DENSE=1 as an independent implementation of the 2x2-tile path).
 //
 // Same role as k_solve_step (cr_kernels.hip) on the trial-step path: solve the current linearization,
 // form the trial point and the step-control scalars of GN / LM / Dogleg.  The system arrives as dense
-// blocks from k_export_normal_eq (2x2 tiles per block): D_i in wHd, block (i+1, i) in wHo, gradient in wg.
-// One workgroup per trajectory runs a block Cholesky in natural order with the blocks in LDS: the
-// augmented matrix [S_i | -g_i | H_{i,i+1}] is reduced row by row, which leaves R_i, y_i = R_i^-T b_i and
-// W_i = R_i^-T H_{i,i+1} in place; S_{i+1} = D_{i+1} - W_i^T W_i.  Back-substitution
-// x_i = R_i^-1 (y_i - W_i x_{i+1}).  A placeholder for a wide-tile cyclic reduction: O(N) dependent
-// blocks instead of O(log N) levels, about 1 ms per solve at N = 100.
+// blocks from k_export_normal_eq: D_i in wHd, block (i+1, i) in wHo, gradient in wg.  The solve is the same
+// cyclic reduction as the tile kernels with one launch per level (k_dense_cr_level forward, k_dense_cr_back
+// backward) and a per-trajectory tail (k_dense_tail).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -28,197 +26,6 @@ __device__ __forceinline__ double dense_block_sum(double v, double* red, int tid
   double t = 0.0;
   for (int k = 0; k < DENSE_WAVES; k++) t += red[k];
   return t;
-}
-
-__global__ __launch_bounds__(DENSE_THREADS) void k_solve_dense(const PlanParams* __restrict__ pp, PlanBuffers pb) {
-  const PlanParams& P = *pp;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (!pb.active[b]) return;
-  const int N = P.N, n = P.n, D = P.D;
-  const int AW = 2 * n + 1;  // augmented width: [S (n) | rhs (1) | H_{i,i+1} (n)]
-  const size_t tsz = (size_t)(N + 1) * n;
-  const double* cur = pb.cur + b * tsz;
-  double* trial = pb.trial + b * tsz;
-  double* delta = pb.delta + b * tsz;
-  double* sc = pb.scal + (size_t)b * SC_COUNT;
-  double* Hd = pb.wHd + (size_t)b * (N + 1) * n * n;
-  double* Ho = pb.wHo + (size_t)b * N * n * n;
-  const double* gv = pb.wg + (size_t)b * tsz;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* xs = smem;                       // [(N+1)][n]  y, then x
-  double* A = xs + tsz;                    // [n][AW]     augmented block
-  double* W = A + (size_t)n * AW;          // [n][n]      W_{i-1}
-  double* red = W + (size_t)n * n;         // [DENSE_WAVES]
-  int* flags = reinterpret_cast<int*>(red + DENSE_WAVES);
-  const bool dogleg = P.opt_type == GPMP2MI_OPT_DOGLEG;
-  const bool resolve = !(dogleg && pb.phase[b] != 0);
-  const int ty = tid >> 4, tx = tid & 15;
-  if (tid == 0) flags[0] = 0;
-  __syncthreads();
-  if (resolve) {
-    if (dogleg) {
-      // g^T H g from the untouched blocks: sum_i g_i^T D_i g_i + 2 g_{i+1}^T H_{i+1,i} g_i
-      double acc = 0.0;
-      for (size_t e = tid; e < (size_t)(N + 1) * n * n; e += DENSE_THREADS) {
-        const int i = (int)(e / (n * n)), r = (int)((e / n) % n), c = (int)(e % n);
-        acc = fma(gv[(size_t)i * n + r] * Hd[e], gv[(size_t)i * n + c], acc);
-      }
-      for (size_t e = tid; e < (size_t)N * n * n; e += DENSE_THREADS) {
-        const int i = (int)(e / (n * n)), r = (int)((e / n) % n), c = (int)(e % n);
-        acc = fma(2.0 * gv[(size_t)(i + 1) * n + r] * Ho[e], gv[(size_t)i * n + c], acc);
-      }
-      acc = dense_block_sum(acc, red, tid);
-      if (tid == 0) sc[SC_GHG] = acc;
-    }
-    const double lam = (P.opt_type == GPMP2MI_OPT_LM) ? pb.lambda[b] : 0.0;
-    // ---- forward: block Cholesky in natural order
-    for (int i = 0; i <= N; i++) {
-      for (int r = ty; r < n; r += 16)
-        for (int c = tx; c < AW; c += 16) {
-          double v;
-          if (c < n) {
-            v = Hd[((size_t)i * n + r) * n + c] + ((r == c) ? lam : 0.0);
-            if (i > 0) {  // Schur complement of the previous block
-              double s = 0.0;
-              for (int k = 0; k < n; k++) s = fma(W[k * n + r], W[k * n + c], s);
-              v -= s;
-            }
-          } else if (c == n) {
-            v = -gv[(size_t)i * n + r];
-            if (i > 0) {
-              double s = 0.0;
-              for (int k = 0; k < n; k++) s = fma(W[k * n + r], xs[(size_t)(i - 1) * n + k], s);
-              v -= s;
-            }
-          } else {
-            v = (i < N) ? Ho[((size_t)i * n + (c - n - 1)) * n + r] : 0.0;  // H_{i,i+1} = block (i+1, i)^T
-          }
-          A[r * AW + c] = v;
-        }
-      __syncthreads();
-      // right-looking elimination on the 16 x 16 thread grid (ty: rows, tx: column strips); row k stays
-      // unscaled (R[k][c] = A[k][c] / sqrt(p_k) is applied when the block is stored): one barrier per pivot
-      for (int k = 0; k < n; k++) {
-        const double piv = A[k * AW + k];
-        if (!(piv > 0.0)) {  // uniform: every thread reads the same LDS value
-          if (tid == 0) pb.notspd[b] = 1;  // k_decide consumes and clears it
-          return;
-        }
-        const double ipiv = 1.0 / piv;
-        for (int j = k + 1 + ty; j < n; j += 16) {
-          const double m = A[k * AW + j] * ipiv;
-          for (int c = tx; c < AW; c += 16)
-            if (c >= j) A[j * AW + c] = fma(-m, A[k * AW + c], A[j * AW + c]);
-        }
-        __syncthreads();
-      }
-      // keep R_i (upper), W_i for the back-substitution; y_i in xs; W_i also stays in LDS for block i+1
-      for (int r = ty; r < n; r += 16) {
-        const double isq = 1.0 / sqrt(A[r * AW + r]);
-        for (int c = tx; c < n; c += 16) {
-          Hd[((size_t)i * n + r) * n + c] = (c >= r) ? A[r * AW + c] * isq : 0.0;
-          const double w = A[r * AW + n + 1 + c] * isq;
-          W[r * n + c] = w;
-          if (i < N) Ho[((size_t)i * n + r) * n + c] = w;
-        }
-        if (tx == 0) xs[(size_t)i * n + r] = A[r * AW + n] * isq;
-      }
-      __syncthreads();
-    }
-    // ---- backward: x_i = R_i^-1 (y_i - W_i x_{i+1}); thread r carries t_r, one barrier per unknown
-    double* xk = W;  // [n] scratch for the unknown being broadcast (W is free now); R_i is staged in A
-    for (int i = N; i >= 0; i--) {
-      for (int e = tid; e < n * n; e += DENSE_THREADS) A[e] = Hd[(size_t)i * n * n + e];
-      double t = 0.0;
-      if (tid < n) {
-        t = xs[(size_t)i * n + tid];
-        if (i < N) {
-          const double* Wi = Ho + (size_t)i * n * n;
-          for (int c = 0; c < n; c++) t = fma(-Wi[tid * n + c], xs[(size_t)(i + 1) * n + c], t);
-        }
-      }
-      __syncthreads();
-      for (int k = n - 1; k >= 0; k--) {
-        if (tid == k) xk[k] = t / A[k * n + k];
-        __syncthreads();
-        if (tid < k) t = fma(-A[tid * n + k], xk[k], t);
-      }
-      if (tid < n) xs[(size_t)i * n + tid] = xk[tid];
-      __syncthreads();
-    }
-    double gd = 0.0, dd = 0.0, gg = 0.0;
-    for (size_t k = tid; k < tsz; k += DENSE_THREADS) {
-      const double x = xs[k], gk = gv[k];
-      delta[k] = x;
-      gd = fma(gk, x, gd);
-      dd = fma(x, x, dd);
-      gg = fma(gk, gk, gg);
-    }
-    gd = dense_block_sum(gd, red, tid);
-    dd = dense_block_sum(dd, red, tid);
-    gg = dense_block_sum(gg, red, tid);
-    if (tid == 0) {
-      sc[SC_GD] = gd;
-      sc[SC_DD] = dd;
-      sc[SC_GG] = gg;
-      sc[SC_GN] = gd;
-      sc[SC_NN] = dd;
-    }
-    __syncthreads();
-  }
-  if (!dogleg) {
-    for (size_t k = tid; k < tsz; k += DENSE_THREADS) {
-      const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
-      const double* zs = cur + (size_t)i * n;
-      const double* dz = xs + (size_t)i * n;
-      trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
-    }
-    return;
-  }
-  // ---- Powell dogleg point for trust radius pb.lambda[b]  (same blend as k_solve_step)
-  const double Delta = pb.lambda[b];
-  const double gg = sc[SC_GG], gHg = sc[SC_GHG], gn = sc[SC_GN], nn = sc[SC_NN];
-  const double step = -gg / gHg;  // dx_u = step * g   (optimizeGradientSearch)
-  const double uu = step * step * gg, un = step * gn;
-  const double DeltaSq = Delta * Delta;
-  double cu, cn, q;  // dx_d = cu * g + cn * dx_n
-  if (DeltaSq < uu) {
-    const double k = sqrt(DeltaSq / uu);
-    cu = k * step;
-    cn = 0.0;
-    q = cu * gg + 0.5 * cu * cu * gHg;
-  } else if (DeltaSq < nn) {
-    const double a = uu - 2. * un + nn, bq = 2. * (un - uu), cq = uu - Delta * Delta;
-    const double sq = sqrt(bq * bq - 4 * a * cq);
-    const double tau1 = (-bq + sq) / (2. * a), tau2 = (-bq - sq) / (2. * a);
-    const double tau = (0.0 <= tau1 && tau1 <= 1.0) ? tau1 : tau2;
-    cu = (1. - tau) * step;
-    cn = tau;
-    q = cu * gg + cn * gn + 0.5 * (cu * cu * gHg - 2.0 * cu * cn * gg - cn * cn * gn);
-  } else {
-    cu = 0.0;
-    cn = 1.0;
-    q = 0.5 * gn;
-  }
-  double xn = 0.0;
-  __syncthreads();
-  for (size_t k = tid; k < tsz; k += DENSE_THREADS) {
-    const double x = cu * gv[k] + cn * delta[k];
-    xs[k] = x;
-    xn = fma(x, x, xn);
-  }
-  __syncthreads();
-  for (size_t k = tid; k < tsz; k += DENSE_THREADS) {
-    const int i = (int)(k / n), rho = (int)(k - (size_t)i * n);
-    const double* zs = cur + (size_t)i * n;
-    const double* dz = xs + (size_t)i * n;
-    trial[k] = (rho < D) ? retract_coord(P.lie != 0, rho, zs, dz) : zs[rho] + dz[rho];
-  }
-  xn = dense_block_sum(xn, red, tid);
-  if (tid == 0) {
-    sc[SC_Q] = q;
-    sc[SC_XNORM] = sqrt(xn);
-  }
 }
 
 // =============================================================================== dense blocks, cyclic reduction
@@ -258,11 +65,17 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_ghg(const PlanParams* _
 }
 
 // Thread (ty, tx) of the 16 x 16 grid owns rows ty + 16 a (a < 3) and columns tx + 16 b (b < 7) of the augmented
-// block [S | b | C_l | C_r] (n <= 48, 3 n + 1 <= 112) and keeps its 21 entries in registers from the first load to the
+// block [S | b | C_l | C_r] (n <= 36) and keeps its 21 entries in registers from the first load to the
 // final store: the Schur complements are register-blocked products over LDS copies of the neighbour's factors, the
 // elimination passes only the pivot row through LDS (double-buffered: one barrier per pivot).
-constexpr int DENSE_NR = 3, DENSE_NC = 7;
-__global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanParams* __restrict__ pp, PlanBuffers pb, int h,
+#ifndef G2_DENSE_GRID
+#define G2_DENSE_GRID 16
+#endif
+constexpr int LVG = G2_DENSE_GRID, LVS = (LVG == 32) ? 5 : (LVG == 16) ? 4 : 3;     // thread grid side of k_dense_cr_level
+constexpr int LVL_THREADS = LVG * LVG;
+constexpr int DENSE_NR = (36 + LVG - 1) / LVG, DENSE_NC = (3 * 36 + 1 + LVG - 1) / LVG;   // 3 x 7 (measured: a 32 x 32 grid
+// pays more for its 16-wavefront barriers than it gains, 448 vs 348 us per solve; one wavefront per block 550 us)
+__global__ __launch_bounds__(LVL_THREADS) void k_dense_cr_level(const PlanParams* __restrict__ pp, PlanBuffers pb, int h,
                                                                  int final) {
   const PlanParams& P = *pp;
   const int N = P.N, n = P.n, tid = threadIdx.x;
@@ -288,8 +101,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
   double* W2 = W1 + nn;                 // [n][n] its other coupling
   double* yn = W2 + nn;                 // [n]    its y
   double* rowbuf = yn + n;              // [2][16 * DENSE_NC] pivot row (double-buffered, padded)
-  double* diag = rowbuf + 2 * 16 * DENSE_NC;   // [n]
-  const int ty = tid >> 4, tx = tid & 15;
+  double* diag = rowbuf + 2 * LVG * DENSE_NC;   // [n]
+  const int ty = tid >> LVS, tx = tid & (LVG - 1);
   // a block is first touched at level 1 (odd) or 2 (even): LM damping and -g enter there
   const bool first = (h == 1) || (h == 2 && !(j & 1));
   const double lam = (first && P.opt_type == GPMP2MI_OPT_LM) ? pb.lambda[b] : 0.0;
@@ -301,7 +114,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     for (int q = 0; q < DENSE_NC; q++) {
       // one unconditional load per entry from a selected (always valid) address: loads behind data-dependent
       // branches would be waited for one by one
-      const int r = ty + 16 * a, c = tx + 16 * q;
+      const int r = ty + LVG * a, c = tx + LVG * q;
       const bool in = r < n && c < AW;
       const int rc = min(r, n - 1);
       const double* src = gv;
@@ -322,11 +135,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     const double* __restrict__ g1 = (side ? Wl : Wr) + (size_t)jn * nn;
     const double* __restrict__ g2 = (side ? Wr : Wl) + (size_t)jn * nn;
     const bool want_c = side ? want_r : want_l;
-    constexpr int NLD = (48 * 48 + DENSE_THREADS - 1) / DENSE_THREADS;   // 9
+    constexpr int NLD = (36 * 36 + LVL_THREADS - 1) / LVL_THREADS;
     double t1[NLD], t2[NLD];
 #pragma unroll
     for (int m = 0; m < NLD; m++) {
-      const int e = tid + DENSE_THREADS * m;
+      const int e = tid + LVL_THREADS * m;
       t1[m] = g1[min(e, nn - 1)];
       t2[m] = want_c ? g2[min(e, nn - 1)] : 0.0;
     }
@@ -334,7 +147,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     __syncthreads();   // the previous side's products are done with W1 / W2
 #pragma unroll
     for (int m = 0; m < NLD; m++) {
-      const int e = tid + DENSE_THREADS * m;
+      const int e = tid + LVL_THREADS * m;
       if (e < nn) { W1[e] = t1[m]; W2[e] = t2[m]; }
     }
     if (tid < n) yn[tid] = ty_;
@@ -346,7 +159,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     const int coff = side ? 2 * n + 1 : n + 1;
 #pragma unroll
     for (int q = 0; q < DENSE_NC; q++) {
-      const int c = tx + 16 * q;
+      const int c = tx + LVG * q;
       on[q] = true;
       if (c < n) { src[q] = W1 + c; stride[q] = n; }
       else if (c == n) { src[q] = yn; stride[q] = 1; }
@@ -355,7 +168,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     }
     int rr[DENSE_NR];
 #pragma unroll
-    for (int a = 0; a < DENSE_NR; a++) rr[a] = min(ty + 16 * a, n - 1);
+    for (int a = 0; a < DENSE_NR; a++) rr[a] = min(ty + LVG * a, n - 1);
     double acc[DENSE_NR][DENSE_NC];
 #pragma unroll
     for (int a = 0; a < DENSE_NR; a++)
@@ -377,14 +190,14 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     for (int a = 0; a < DENSE_NR; a++)
 #pragma unroll
       for (int q = 0; q < DENSE_NC; q++)
-        if (on[q] && ty + 16 * a < n) reg[a][q] -= acc[a][q];
+        if (on[q] && ty + LVG * a < n) reg[a][q] -= acc[a][q];
   }
   if (!elim) {
 #pragma unroll
     for (int a = 0; a < DENSE_NR; a++)
 #pragma unroll
       for (int q = 0; q < DENSE_NC; q++) {
-        const int r = ty + 16 * a, c = tx + 16 * q;
+        const int r = ty + LVG * a, c = tx + LVG * q;
         if (r < n && c < n) Hd[(size_t)j * nn + r * n + c] = reg[a][q];
         if (r < n && c == n) rb[(size_t)j * n + r] = reg[a][q];
       }
@@ -393,10 +206,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
   // elimination: the owners of row k publish it, everybody reads the pivot, its own columns of the row and the
   // multipliers of its own rows (A[k][r], upper triangle) from that copy; entries below the diagonal of S are
   // never read again, so they are updated along without a test
-  constexpr int RB = 16 * DENSE_NC;   // padded row buffer: columns >= AW hold don't-care values
+  constexpr int RB = LVG * DENSE_NC;   // padded row buffer: columns >= AW hold don't-care values
   if (ty == 0) {
 #pragma unroll
-    for (int q = 0; q < DENSE_NC; q++) rowbuf[tx + 16 * q] = reg[0][q];
+    for (int q = 0; q < DENSE_NC; q++) rowbuf[tx + LVG * q] = reg[0][q];
   }
   __syncthreads();
   for (int k = 0; k < n; k++) {
@@ -409,20 +222,20 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
     const double ipiv = 1.0 / piv;
     double rk[DENSE_NC], mk[DENSE_NR];
 #pragma unroll
-    for (int q = 0; q < DENSE_NC; q++) rk[q] = row[tx + 16 * q];
+    for (int q = 0; q < DENSE_NC; q++) rk[q] = row[tx + LVG * q];
 #pragma unroll
-    for (int a = 0; a < DENSE_NR; a++) mk[a] = row[min(ty + 16 * a, n - 1)];
+    for (int a = 0; a < DENSE_NR; a++) mk[a] = row[min(ty + LVG * a, n - 1)];
     double* nxt = rowbuf + ((k + 1) & 1) * RB;
 #pragma unroll
     for (int a = 0; a < DENSE_NR; a++) {
-      const int r = ty + 16 * a;
+      const int r = ty + LVG * a;
       if (r > k && r < n) {
         const double m = mk[a] * ipiv;
 #pragma unroll
         for (int q = 0; q < DENSE_NC; q++) reg[a][q] = fma(-m, rk[q], reg[a][q]);
         if (r == k + 1) {
 #pragma unroll
-          for (int q = 0; q < DENSE_NC; q++) nxt[tx + 16 * q] = reg[a][q];
+          for (int q = 0; q < DENSE_NC; q++) nxt[tx + LVG * q] = reg[a][q];
         }
       }
     }
@@ -432,16 +245,16 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_cr_level(const PlanPara
   for (int a = 0; a < DENSE_NR; a++)
 #pragma unroll
     for (int q = 0; q < DENSE_NC; q++)
-      if (ty + 16 * a < n && ty + 16 * a == tx + 16 * q) diag[ty + 16 * a] = reg[a][q];
+      if (ty + LVG * a < n && ty + LVG * a == tx + LVG * q) diag[ty + LVG * a] = reg[a][q];
   __syncthreads();
 #pragma unroll
   for (int a = 0; a < DENSE_NR; a++) {
-    const int r = ty + 16 * a;
+    const int r = ty + LVG * a;
     if (r >= n) continue;
     const double isq = 1.0 / sqrt(diag[r]);
 #pragma unroll
     for (int q = 0; q < DENSE_NC; q++) {
-      const int c = tx + 16 * q;
+      const int c = tx + LVG * q;
       const double v = reg[a][q] * isq;
       if (c < n) Hd[(size_t)j * nn + r * n + c] = (c >= r) ? v : 0.0;
       else if (c == n) yv[(size_t)j * n + r] = v;
@@ -602,9 +415,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void k_dense_tail(const PlanParams* 
 }
 
 // cyclic-reduction form of the dense solve: g^T H g (Dogleg), forward levels, backward levels, tail
-int launch_solve_dense_cr(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
+int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
   const int n = hp.n, N = hp.N;
-  const size_t sh_level = (2 * (size_t)n * n + n + 2 * 16 * DENSE_NC + n) * sizeof(double);
+  const size_t sh_level = (2 * (size_t)n * n + n + 2 * LVG * DENSE_NC + n) * sizeof(double);
   if (n > 36) {
     set_error("dense block solver: blocks wider than 36 are not instantiated");
     return GPMP2MI_ERR_UNSUPPORTED;
@@ -621,7 +434,7 @@ int launch_solve_dense_cr(const PlanParams& hp, const PlanBuffers& pb, hipStream
   for (int h = 1; h <= hfinal; h <<= 1) {
     const int final = h == hfinal;
     const int countE = final ? 1 : ((N / h) + 1) / 2, countU = (final || h == 1) ? 0 : (N / (2 * h)) + 1;
-    k_dense_cr_level<<<dim3(hp.B * (countE + countU)), dim3(DENSE_THREADS), sh_level, st>>>(pb.params, pb, h, final);
+    k_dense_cr_level<<<dim3(hp.B * (countE + countU)), dim3(LVL_THREADS), sh_level, st>>>(pb.params, pb, h, final);
   }
   for (int h = hfinal; h >= 1; h >>= 1) {
     const int final = h == hfinal;
@@ -629,18 +442,6 @@ int launch_solve_dense_cr(const PlanParams& hp, const PlanBuffers& pb, hipStream
     k_dense_cr_back<<<dim3(hp.B * count), dim3(64), sh_back, st>>>(pb.params, pb, h, final);
   }
   k_dense_tail<<<dim3(hp.B), dim3(DENSE_THREADS), sh_tail, st>>>(pb.params, pb);
-  G2_HIP(hipGetLastError());
-  return GPMP2MI_OK;
-}
-
-int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
-  const int n = hp.n;
-  const size_t shmem = ((size_t)(hp.N + 1) * n + (size_t)n * (2 * n + 1) + (size_t)n * n + DENSE_WAVES + 2) * sizeof(double);
-  if (shmem > 150 * 1024) {
-    set_error("total_step too large for the LDS-resident dense solve");
-    return GPMP2MI_ERR_UNSUPPORTED;
-  }
-  k_solve_dense<<<dim3(hp.B), dim3(DENSE_THREADS), shmem, st>>>(pb.params, pb);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }

@@ -97,8 +97,8 @@ struct PlanBuffers {
   int* goal_on;            // [B] 0 after removeGoalConfigAndVel
   // dense block-tridiagonal system and its factors (wide path only; n = 2 dof)
   double* wHd;             // [B][N+1][n][n]   diagonal blocks, then their upper Cholesky factors R_i
-  double* wHo;             // [B][N][n][n]     block (i+1, i), then W_i = R_i^-T H_{i,i+1}
-  double* wg;              // [B][N+1][n]      gradient, then y_i
+  double* wHo;             // [B][N][n][n]     block (i+1, i) (read only)
+  double* wg;              // [B][N+1][n]      gradient (read only)
   double* wWl;             // [B][N+1][n][n]   dense cyclic reduction: W_l = R^-T C_l of every eliminated block
   double* wWr;             // [B][N+1][n][n]   ... W_r
   double* wy;              // [B][N+1][n]      ... y = R^-T b
@@ -156,7 +156,6 @@ int launch_gn_step_cr(const PlanParams& hp, const PlanBuffers& pb, int pass, hip
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st);
 int launch_finish_trial(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 int launch_solve_dense(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
-int launch_solve_dense_cr(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st);
 // wide_cr.h (8 <= dof <= 11 on 2x2 tiles)
 int launch_assemble_wide(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                          const int* active, hipStream_t st);
