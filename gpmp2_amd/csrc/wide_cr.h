@@ -3,10 +3,11 @@
 // Included at the end of cr_kernels.hip (inside namespace g2).  A block is a 32 x 32 matrix held as
 // 2 x 2 MFMA-layout tiles (WTile); element (row, col) lives in tile (row >> 4, col >> 4).  The right-hand
 // side rides in column 31.  Everything mirrors the one-tile kernels: k_assemble_wide forms the block of
-// one support state (four Assembler passes with tile offsets) and eliminates the odd blocks (level 1);
-// k_solve_step_wide runs levels 2.. of the reduction, the back-substitution and the trial-step tail of
-// the GN / LM / Dogleg driver.  Not yet here: level-2 fusion into the assemble kernel, the chip-wide
-// back-substitution tail, the fused GN step kernel (GN runs through the trial-step driver).
+// one support state (four Assembler passes with tile offsets; the interpolated factors of Pose2 robots as
+// E^T G E congruences on the matrix cores) and eliminates the odd blocks (level 1); k_cr_level_wide runs forward
+// levels 2 and 4 chip-wide; k_solve_step_wide runs the levels above, the back-substitution down to the multiples
+// of 8 and (Dogleg) the whole trial-step tail; k_finish_trial_wide finishes the back-substitution, the step and the
+// trial point chip-wide for GN / LM (GN runs through the trial-step driver).
 #pragma once
 
 struct WTile {
