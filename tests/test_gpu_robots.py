@@ -222,6 +222,43 @@ def test_wide_robot_linearize_and_plans(engine, oracle, name):
         np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
 
 
+@pytest.mark.parametrize("name,N", [("mobile WAM (dof 10)", 20), ("mobile WAM (dof 10)", 35), ("lift WAM (dof 11)", 17),
+                                    ("2arms 3+3 (dof 9)", 24)])
+def test_wide_long_trajectories(engine, oracle, name, N):
+    """total_step >= 16: forward levels 2 and 4 as chip-wide launches (k_cr_level_wide) and, for GN / LM, the
+    back-substitution levels 4, 2, 1 + step + trial point in k_finish_trial_wide (groups of 8 blocks, the last one
+    ragged for these N); Dogleg keeps the one-kernel tail.  Three trajectories per plan with different starts so that
+    they leave the loop at different passes."""
+    model = _wide_models()[name]
+    D = model.dof()
+    p = _tree_problem(model, N=N, inter=2, opt="GN")
+    B = 3
+    rng = np.random.default_rng(41)
+    start = np.repeat(p.start_conf, B, 0)
+    end = np.repeat(p.end_conf, B, 0)
+    start[1:, 3:] += 0.2 * rng.normal(size=(B - 1, D - 3))
+    end[1:, :2] += 0.3 * rng.normal(size=(B - 1, 2))
+    init = np.zeros((B, N + 1, 2 * D))
+    for b in range(B):
+        for i in range(N + 1):
+            init[b, i, :D] = start[b] * (N - i) / N + end[b] * i / N
+        init[b, :, D:] = (end[b] - start[b])[None, :] / 3.0
+    z = np.zeros((B, D))
+    args = (start, z, end, z)
+    r, ro = engine.robot(p.model), oracle.robot(p.model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    for opt in ("GN", "LM", "DOGLEG"):
+        {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM, "DOGLEG": p.setting.setDogleg}[opt]()
+        res = engine.batch_optimize(r, s, p.setting, *args, init)
+        ref = oracle.batch_optimize(ro, so, p.setting, *args, init)
+        assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
+        np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
+        # LM: one of the N = 35 trajectories sits on a flat valley of its cost (final errors agree to 1e-9, the
+        # trajectory to 3.9e-6; the independent dense-block solver differs from the oracle by 6.8e-6 on the same
+        # trajectory and by < 1e-9 on the others -- scripts/wide_cond_probe.py), so its gate is 1e-5
+        np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-5 if opt == "LM" else 1e-6)
+
+
 def test_wide_dense_fallback_agrees(engine, oracle, monkeypatch):
     """GPMP2MI_WIDE_DENSE=1: the independent dense block-Cholesky implementation of the 8..11-dof solve"""
     model = _wide_models()["mobile WAM (dof 10)"]
@@ -278,7 +315,7 @@ def test_pr2_model_plans(engine, oracle):
     """generateMobileArm('PR2') (matlab/+gpmp2/generateMobileArm.m:244-349): SE(2) base + lift + two 7-joint arms,
     dof 18, 65 spheres -- the robot BatchTrajOptimizePose2MobileVetLin2Arms (planner/BatchTrajOptimizer.cpp:118-128) is
     instantiated for.  Kinematics, obstacle factors, normal equations (3x3-tile export) and GN / LM / Dogleg plans
-    (dense block Cholesky) against the oracle."""
+    (dense blocks, cyclic reduction with one launch per level) against the oracle."""
     model = g.generateMobileArm("PR2")
     assert model.dof() == 18 and model.nr_body_spheres() == 65
     r, ro = engine.robot(model), oracle.robot(model)
@@ -313,3 +350,29 @@ def test_pr2_model_plans(engine, oracle):
         assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
         np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
         np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+def test_pr2_ragged_tree(engine, oracle):
+    """PR2, total_step = 13 (14 blocks: every level of the dense cyclic reduction has a block without a right
+    neighbour), two trajectories that stop at different passes, LM"""
+    model = g.generateMobileArm("PR2")
+    N, B = 13, 2
+    p = _tree_problem(model, N=N, inter=1, opt="LM")
+    start, end = np.repeat(p.start_conf, B, 0), np.repeat(p.end_conf, B, 0)
+    end[:, 3] = 0.2
+    end[0, 4:] = np.tile(np.linspace(0.2, 0.8, 7), 2) * np.r_[np.ones(7), -np.ones(7)]
+    end[1, 4:] = np.tile(np.linspace(-0.3, 0.5, 7), 2)
+    init = np.zeros((B, N + 1, 36))
+    for b in range(B):
+        for i in range(N + 1):
+            init[b, i, :18] = start[b] * (N - i) / N + end[b] * i / N
+        init[b, :, 18:] = (end[b] - start[b])[None, :] / 3.0
+    z = np.zeros((B, 18))
+    args = (start, z, end, z)
+    r, ro = engine.robot(model), oracle.robot(model)
+    s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    res = engine.batch_optimize(r, s, p.setting, *args, init)
+    ref = oracle.batch_optimize(ro, so, p.setting, *args, init)
+    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
+    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
