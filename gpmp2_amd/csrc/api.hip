@@ -409,7 +409,7 @@ int gpmp2mi_sdf_create(int dim, const double origin[3], double cell, int nx, int
   const double* src = to_zyx(vox, layout, nx, ny, nz, tmp);
   G2_HIP(hipMemcpy(s->plain, src, (size_t)nx * ny * nz * sizeof(double), hipMemcpyHostToDevice));
   G2_TRY(launch_sdf_pack(s->h, s->cells, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   *out = s.release();
   return GPMP2MI_OK;
 }
@@ -429,7 +429,7 @@ int gpmp2mi_sdf_field_from_occupancy(int dim, int nx, int ny, int nz, const doub
   G2_TRY(wa.alloc(n));
   G2_TRY(wb.alloc(n));
   G2_TRY(launch_sdf_from_occupancy(nx, ny, nz, d_occ.p, cell, wa.p, wb.p, d_field.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   return d_field.download(field);
 }
 
@@ -451,7 +451,7 @@ int gpmp2mi_sdf_create_from_occupancy(int dim, const double origin[3], double ce
   G2_TRY(wb.alloc(n));
   G2_TRY(launch_sdf_from_occupancy(nx, ny, nz, d_occ.p, cell, wa.p, wb.p, s->plain, nullptr));
   G2_TRY(launch_sdf_pack(s->h, s->cells, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   *out = s.release();
   return GPMP2MI_OK;
 }
@@ -507,7 +507,7 @@ int gpmp2mi_sdf_query(const gpmp2mi_sdf* s, int M, const double* pts, double* di
   if (grad) G2_TRY(dg.alloc((size_t)M * s->h.dim));
   if (inr) G2_TRY(di.alloc(M));
   G2_TRY(launch_sdf_query(s->h, M, dp.p, dd.p, dg.p, di.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dd.download(dist));
   G2_TRY(dg.download(grad));
   G2_TRY(di.download(inr));
@@ -553,7 +553,7 @@ int gpmp2mi_forward_kinematics(const gpmp2mi_robot* r, int M, const double* conf
   G2_TRY(dp.alloc((size_t)M * L * 16));
   if (J) G2_TRY(dj.alloc((size_t)M * L * 6 * D));
   G2_TRY(launch_fk(r->h, r->d, M, dq.p, dp.p, dj.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dp.download(poses));
   G2_TRY(dj.download(J));
   return GPMP2MI_OK;
@@ -569,7 +569,7 @@ int gpmp2mi_sphere_centers(const gpmp2mi_robot* r, int M, const double* conf, do
   G2_TRY(dc.alloc((size_t)M * S * 3));
   if (J) G2_TRY(dj.alloc((size_t)M * S * 3 * D));
   G2_TRY(launch_sphere_centers(r->h, r->d, M, dq.p, dc.p, dj.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dc.download(centers));
   G2_TRY(dj.download(J));
   return GPMP2MI_OK;
@@ -592,7 +592,7 @@ int gpmp2mi_workspace_prior_factor(const gpmp2mi_robot* r, int mode, int joint, 
   if (H) G2_TRY(dh.alloc((size_t)M * rows * D));
   G2_TRY(launch_fk(r->h, r->d, M, dq.p, dp.p, dj.p, nullptr));
   G2_TRY(launch_workspace_prior(mode, joint, L, D, M, dd.p, dp.p, dj.p, de.p, dh.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(dh.download(H));
   return GPMP2MI_OK;
@@ -628,7 +628,7 @@ int gpmp2mi_self_collision_factor(const gpmp2mi_robot* r, int n_pairs, const dou
   if (H) G2_TRY(dh.alloc((size_t)M * n_pairs * D));
   G2_TRY(launch_sphere_centers(r->h, r->d, M, dq.p, dc.p, dj.p, nullptr));
   G2_TRY(launch_self_collision(n_pairs, S, D, M, dd.p, dr.p, dc.p, dj.p, de.p, dh.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(dh.download(H));
   return GPMP2MI_OK;
@@ -645,7 +645,7 @@ int gpmp2mi_obstacle_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, double
   G2_TRY(de.alloc((size_t)M * S));
   if (H1) G2_TRY(dh.alloc((size_t)M * S * D));
   G2_TRY(launch_obstacle(r->h, r->d, s->h, eps, M, dq.p, de.p, dh.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(dh.download(H1));
   return GPMP2MI_OK;
@@ -676,7 +676,7 @@ int gpmp2mi_obstacle_gp_factor(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, dou
   }
   const GpCoef gc = gp_coef(delta_t, tau);
   G2_TRY(launch_obstacle_gp(r->h, r->d, s->h, eps, gc, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(h1.download(H1));
   G2_TRY(h2.download(H2));
@@ -707,7 +707,7 @@ int gpmp2mi_gp_prior_factor(int D, int lie, double dt, int M, const double* c1, 
   }
   if (lie) G2_TRY(launch_gp_prior_lie(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
   else G2_TRY(launch_gp_prior_linear(D, dt, M, a.p, b.p, c.p, d.p, de.p, h1.p, h2.p, h3.p, h4.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(h1.download(H1));
   G2_TRY(h2.download(H2));
@@ -731,7 +731,7 @@ int gpmp2mi_gp_interpolate(int D, int lie, const double* Qc, double dt, double t
   if (vel) G2_TRY(ov.alloc((size_t)M * D));
   if (lie) G2_TRY(launch_gp_interp_lie(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
   else G2_TRY(launch_gp_interp_linear(D, gp_coef(dt, tau), M, a.p, b.p, c.p, d.p, oc.p, ov.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(oc.download(conf));
   G2_TRY(ov.download(vel));
   return GPMP2MI_OK;
@@ -760,7 +760,7 @@ int gpmp2mi_interpolate_traj(int D, int lie, const double* Qc, double dt, int in
   G2_TRY(a.upload(traj, (size_t)B * (N + 1) * 2 * D));
   G2_TRY(o.alloc((size_t)B * Mo * 2 * D));
   G2_TRY(gpmp2mi_interpolate_traj_dev(D, lie, dt, inter, B, N, start, end, a.p, o.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(o.download(out));
   return GPMP2MI_OK;
 }
@@ -777,7 +777,7 @@ int gpmp2mi_vehicle_dynamics_factor(int D, int lie, int M, const double* conf, c
   if (Hp) G2_TRY(dp.alloc((size_t)M * D));
   if (Hv) G2_TRY(dh.alloc((size_t)M * D));
   G2_TRY(launch_vehicle_dynamics(D, lie, M, dc.p, dv.p, de.p, dp.p, dh.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(dp.download(Hp));
   G2_TRY(dh.download(Hv));
@@ -797,7 +797,7 @@ int gpmp2mi_joint_limit_factor(int D, const double* down, const double* up, cons
   G2_TRY(de.alloc((size_t)M * D));
   if (Hd) G2_TRY(dh.alloc((size_t)M * D));
   G2_TRY(launch_joint_limit(D, a.p, b.p, c.p, M, dx.p, de.p, dh.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   G2_TRY(dh.download(Hd));
   return GPMP2MI_OK;
@@ -818,7 +818,7 @@ int gpmp2mi_block_tridiag_solve(int B, int nblk, int n, const double* Hd, const 
   G2_TRY(ds.alloc((size_t)B * nblk * 512));
   G2_TRY(dk.alloc(B));
   G2_TRY(launch_block_tridiag_solve(B, nblk, n, dd.p, dob.p, db.p, dx.p, dk.p, ds.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dx.download(x));
   G2_TRY(dk.download(ok));
   return GPMP2MI_OK;
@@ -1325,7 +1325,7 @@ int gpmp2mi_plan_graph_error(gpmp2mi_plan* p, const double* traj, double* err) {
   G2_TRY(de.alloc(p->hp.B));
   G2_TRY(plan_linearize(p, dt.p, 1, nullptr, nullptr));
   G2_TRY(launch_error_reduce(p->hp, p->pb, dt.p, 1, de.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(de.download(err));
   return GPMP2MI_OK;
 }
@@ -1346,7 +1346,7 @@ int gpmp2mi_plan_linearize(gpmp2mi_plan* p, const double* traj, double* Hdiag, d
   G2_TRY(plan_linearize(p, dt.p, 1, nullptr, nullptr));
   G2_TRY(launch_export_normal_eq(P, pb, dt.p, 1, dd.p, dob.p, dg.p, nullptr));
   if (err) G2_TRY(launch_error_reduce(P, pb, dt.p, 1, de.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dd.download(Hdiag));
   G2_TRY(dob.download(Hoff));
   G2_TRY(dg.download(g));
@@ -1505,7 +1505,7 @@ int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
   G2_TRY(di.upload(in64, 64));
   G2_TRY(dout.alloc(512));
   G2_TRY(launch_debug_crosslane(di.p, dout.p, nullptr));
-  G2_HIP(hipDeviceSynchronize());
+  G2_HIP(hipStreamSynchronize(nullptr));
   G2_TRY(dout.download(out512));
   return GPMP2MI_OK;
 }

@@ -135,23 +135,6 @@ struct Assembler {
     }
   }
 
-  // sum_{a,b} L[a][kr] Qc^-1[a][b] R[b][kc] where L / R are either the identity (ML == nullptr) or
-  // the DxD block-diagonal Jacobian diag(M (3x3, row-major), sign * I)
-  __device__ __forceinline__ double lie_quad(const double* ML, double sL, const double* MR, double sR, int kr,
-                                             int kc) const {
-    double acc = 0.0;
-    const int a0 = (ML && kr < 3) ? 0 : kr, a1 = (ML && kr < 3) ? 3 : kr + 1;
-    const int b0 = (MR && kc < 3) ? 0 : kc, b1 = (MR && kc < 3) ? 3 : kc + 1;
-    for (int a = a0; a < a1; a++) {
-      const double la = !ML ? 1.0 : (kr < 3 ? ML[a * 3 + kr] : sL);
-      for (int bb = b0; bb < b1; bb++) {
-        const double rb_ = !MR ? 1.0 : (kc < 3 ? MR[bb * 3 + kc] : sR);
-        acc = fma(la * rb_, P.Qc_inv[a * D + bb], acc);
-      }
-    }
-    return acc;
-  }
-
   // (Hint^T g)[kr]
   __device__ __forceinline__ static double hint_vec(const double* pt, const double* M, double s, int kr) {
     const double* gp_ = pt + NG;
@@ -203,6 +186,34 @@ struct Assembler {
       if (16 * rt + 4 * k >= D) continue;
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A.r[k], B.r[k], acc, 0, 0, 0);
     }
+  }
+  // The GP prior of a Pose2 robot the same way: its Hessian blocks are quadrant-weighted congruences X^T Qc^-1 Y with
+  // X, Y = [diag(J (3x3), s I) | I] (D x n): J = J3, s = +1 for the second state of the interval (Bm), J = J1, s = -1
+  // for the first (A); the 2 x 2 weights of Q^-1(delta_t) and Phi are applied per quadrant afterwards (build_tiles).
+  __device__ __forceinline__ Tile gp_tile(const double* J, double s, int rt, int cbase) const {
+    const int j = cbase + (lane & 15), av = j >= D, kk = j - av * D;
+    Tile T;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int a = 16 * rt + (lane >> 4) + 4 * k;
+      const bool pose = !av && a < 3 && kk < 3;
+      const double m = J[pose ? a * 3 + kk : 0];
+      const double v = pose ? m : ((a == kk && (av || a >= 3)) ? (av ? 1.0 : s) : 0.0);
+      T.r[k] = (a < D && j < n) ? v : 0.0;
+    }
+    return T;
+  }
+  __device__ __forceinline__ Tile qc_tile(int rt, int ct) const {
+    const int a2 = 16 * ct + (lane & 15);
+    Tile T;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int a = 16 * rt + (lane >> 4) + 4 * k;
+      const bool in = a < D && a2 < D;
+      const double v = P.Qc_inv[in ? a * D + a2 : 0];
+      T.r[k] = in ? v : 0.0;
+    }
+    return T;
   }
   // acc += E_L^T G E_R for one output tile; G[rb][ra], EL[ra], ER[rb] = tiles along the configuration dimension
   __device__ __forceinline__ static void congruence(const Tile (&G)[KT][KT], const Tile (&EL)[KT], const Tile (&ER)[KT],
@@ -452,25 +463,44 @@ struct Assembler {
         hlk[k] = valid[k] ? hlk[k] : 0.0;
       }
     } else {
+    // GP prior blocks: A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]];
+    // the four congruences with Qc^-1 on the matrix cores, the quadrant weights of W = Q^-1 (x) Qc^-1 per entry
+    v4d xdp = {0.0, 0.0, 0.0, 0.0}, xl = xdp, xdn = xdp, xr = xdp;
+    {
+      Tile Qt[KT][KT], EL[KT], ER[KT];
+#pragma unroll
+      for (int ra = 0; ra < KT; ra++)
+#pragma unroll
+        for (int rb = 0; rb < KT; rb++) Qt[rb][ra] = qc_tile(rb, ra);
+      if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
+#pragma unroll
+        for (int ra = 0; ra < KT; ra++) { EL[ra] = gp_tile(J3i, 1.0, ra, row0); ER[ra] = gp_tile(J3i, 1.0, ra, col0); }
+        congruence(Qt, EL, ER, xdp);
+        if (want_c) {
+#pragma unroll
+          for (int ra = 0; ra < KT; ra++) ER[ra] = gp_tile(J1i, -1.0, ra, col0);
+          congruence(Qt, EL, ER, xl);
+        }
+      }
+      if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
+#pragma unroll
+        for (int ra = 0; ra < KT; ra++) { EL[ra] = gp_tile(J1n, -1.0, ra, row0); ER[ra] = gp_tile(J1n, -1.0, ra, col0); }
+        congruence(Qt, EL, ER, xdn);
+        if (want_c) {
+#pragma unroll
+          for (int ra = 0; ra < KT; ra++) ER[ra] = gp_tile(J3n, 1.0, ra, col0);
+          congruence(Qt, EL, ER, xr);
+        }
+      }
+    }
+    const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if (!valid[k]) continue;
-      const int ar = a_row[k], kr = k_row[k];
-      double d = 0.0, hr = 0.0, hl = 0.0;
-      {
-        // A = d r / d z_first = [[J1, -dt I],[0, -I]],  Bm = d r / d z_second = [[J3, 0],[0, I]]
-        const double cAxv = -(dt * w0 + w1), cAvv = dt * dt * w0 + 2.0 * dt * w1 + w3, cOvv = -(dt * w1 + w3);
-        if (has_prev) {  // Bm^T W Bm of interval i ; H_{i,i-1} = Bm^T W A of interval i
-          const double* L = ar ? nullptr : J3i;
-          d += (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * lie_quad(L, 1.0, ac ? nullptr : J3i, 1.0, kr, kc);
-          if (want_c) hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * lie_quad(L, 1.0, ac ? nullptr : J1i, -1.0, kr, kc);
-        }
-        if (has_next) {  // A^T W A of interval i+1 ; H_{i,i+1} = A^T W Bm of interval i+1
-          const double* L = ar ? nullptr : J1n;
-          d += (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * lie_quad(L, -1.0, ac ? nullptr : J1n, -1.0, kr, kc);
-          if (want_c) hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * lie_quad(L, -1.0, ac ? nullptr : J3n, 1.0, kr, kc);
-        }
-      }
+      const int ar = a_row[k];
+      double d = (ar ? (ac ? w3 : w1) : (ac ? w1 : w0)) * xdp[k] + (ar ? (ac ? cAvv : cAxv) : (ac ? cAxv : w0)) * xdn[k];
+      const double hl = (ar ? (ac ? cOvv : w1) : (ac ? cAxv : w0)) * xl[k];
+      const double hr = (ar ? (ac ? cOvv : cAxv) : (ac ? w1 : w0)) * xr[k];
       if (!ar && !ac) d += si.pt(I)[tri[k]];  // unary obstacle factor at state i
       dk[k] = d;
       hrk[k] = hr;
