@@ -16,7 +16,12 @@ __device__ __forceinline__ double misc_error_partial(const PlanParams& P, const 
                                                      const double* __restrict__ tr, int tid, int nthr) {
   const int D = P.D, n = P.n, N = P.N;
   double acc = 0.0;
-  for (int idx = tid; idx < (N + 1) * n; idx += nthr) {
+  // without limit / dynamics factors and replanner priors only the first and the last state carry terms
+  const int nxp = pb.xp_n[b];
+  const bool every_state = P.flag_pos_limit || P.flag_vel_limit || P.vdyn_w > 0.0 || nxp > 0;
+  const int count = every_state ? (N + 1) * n : (N > 0 ? 2 * n : n);
+  for (int q = tid; q < count; q += nthr) {
+    const int idx = (every_state || q < n) ? q : N * n + (q - n);
     const int i = idx / n, rho = idx - i * n;
     const int a = rho >= D, k = rho - a * D;
     const double z = tr[idx];
@@ -31,7 +36,7 @@ __device__ __forceinline__ double misc_error_partial(const PlanParams& P, const 
       }
       acc += (a ? P.vel_prior_w : P.conf_prior_w) * d * d;
     }
-    for (int e = 0; e < pb.xp_n[b]; e++) {  // replanner state priors: r^T W r, row k's share
+    for (int e = 0; e < nxp; e++) {  // replanner state priors: r^T W r, row k's share
       const size_t xe = (size_t)b * XP_MAX + e;
       if (pb.xp_state[xe] != i || (a && !pb.xp_has_vel[xe])) continue;
       const double* Wm = pb.xp_info + (xe * 2 + a) * D * D + (size_t)k * D;

@@ -414,6 +414,17 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
   // action: 0 keep iterating, 1 finish with cur, 2 finish with last; accept: copy trial -> cur
   int action = 0, accept = 0;
 
+  // The trajectory moves at the end (last = cur, cur = trial, result = ...) read cur and trial; requested here, they
+  // arrive while the error is being summed instead of one dependent load-store pair after another behind the decision.
+  constexpr int PF = 10;   // prefetched elements per thread and array (covers (N + 1) n <= 2560)
+  double pf_cur[PF], pf_trial[PF];
+#pragma unroll
+  for (int m = 0; m < PF; m++) {
+    const size_t k = tid + (size_t)m * 256;
+    pf_cur[m] = (k < tsz) ? cur[k] : 0.0;
+    pf_trial[m] = (!init && k < tsz) ? trial[k] : 0.0;
+  }
+
   const bool failed = !init && pb.notspd[b] != 0;
   double err_sum = 0.0;
   if (!failed) {
@@ -539,21 +550,42 @@ __device__ __forceinline__ void decide_body(const PlanParams& P, const PlanBuffe
   __syncthreads();
   action = dec[0];
   accept = dec[1];
+  // (pf_cur / pf_trial hold the first PF * 256 elements; longer trajectories finish with plain loads)
   if (accept) {
     if (action == 2) {
       // rollback: the result is the pre-step `cur`; nothing else reads cur afterwards
-      for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
+#pragma unroll
+      for (int m = 0; m < PF; m++) {
+        const size_t k = tid + (size_t)m * 256;
+        if (k < tsz) result[k] = pf_cur[m];
+      }
+      for (size_t k = tid + (size_t)PF * 256; k < tsz; k += 256) result[k] = cur[k];
     } else {
-      for (size_t k = tid; k < tsz; k += blockDim.x) {
+#pragma unroll
+      for (int m = 0; m < PF; m++) {
+        const size_t k = tid + (size_t)m * 256;
+        if (k < tsz) {
+          last[k] = pf_cur[m];
+          cur[k] = pf_trial[m];
+          if (action == 1) result[k] = pf_trial[m];
+        }
+      }
+      for (size_t k = tid + (size_t)PF * 256; k < tsz; k += 256) {
+        const double t = trial[k];
         last[k] = cur[k];
-        cur[k] = trial[k];
+        cur[k] = t;
+        if (action == 1) result[k] = t;
       }
       if (tid == 0) pb.which[b] = wh ^ 1;  // the trial linearization is now the one at cur
     }
-  }
-  if (action == 1) {
-    for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = cur[k];
-  } else if (action == 2 && !accept) {
+  } else if (action == 1) {
+#pragma unroll
+    for (int m = 0; m < PF; m++) {
+      const size_t k = tid + (size_t)m * 256;
+      if (k < tsz) result[k] = pf_cur[m];
+    }
+    for (size_t k = tid + (size_t)PF * 256; k < tsz; k += 256) result[k] = cur[k];
+  } else if (action == 2) {
     for (size_t k = tid; k < tsz; k += blockDim.x) result[k] = last[k];
   }
   if (tid == 0) {
