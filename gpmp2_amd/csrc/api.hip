@@ -839,7 +839,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 18");
   const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: 2x2-tile cyclic reduction (dof <= 11)
-  const bool dense_only = D > 11; // 12 <= dof <= 18 (PR2): dense normal equations + dense block Cholesky
+  const bool dense_only = D > 11; // 12 <= dof <= 18 (PR2): dense normal equations + cyclic reduction over dense blocks
   {
     // the assembler stages an interval with at most NLD2 16-B loads per lane (assembler.h: 6, 9 on the wide path)
     const int nd = D * (D + 1) / 2 + D + 1 + ((robot->h.base_dof == 3 && s->obs_check_inter > 0) ? 36 : 0);
@@ -1232,7 +1232,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
     p->timer.close(st);
     for (int pass = 1; pass < max_pass; pass++) {
       if (P.wide && p->wide_dense) {
-        // fallback / A-B: dense normal equations + dense block Cholesky in natural order
+        // dof 12..18, or A-B for 8..11: dense normal equations + cyclic reduction over dense blocks
         p->timer.begin("export_dense", st);
         G2_TRY(launch_export_normal_eq(P, pb, pb.cur, 0, pb.wHd, pb.wHo, pb.wg, st, pb.active));
         p->timer.begin("solve_dense", st);

@@ -18,7 +18,7 @@ struct PlanParams {
       lie;
   int lin_split;                       // 2: k_linearize splits the spheres of a point over 2 wavefronts (fixed-base arms)
   int end_conf_prior_off;              // 1: no PriorFactor on x_N (a goal / workspace factor stands in)
-  int wide;                            // 2 dof > 15: dense block path (k_export_normal_eq + k_solve_dense)
+  int wide;                            // 2 dof > 15: blocks wider than one tile (2x2-tile kernels of wide_cr.h, or the dense path of dense_kernels.hip)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
   int spart_groups;                    // workgroups per trajectory of k_finish_trial(_wide)
   int wide_h0;                         // wide blocks: first forward level k_solve_step_wide runs itself (levels below: k_cr_level_wide)
