@@ -119,7 +119,11 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
     const double eps = P.eps;
     double hx, hy, hz, r;
     auto accumulate = [&](const double (&Jc)[D][3], auto nc) {
-      constexpr int NC = decltype(nc)::value;  // columns >= NC of this sphere's Jacobian are zero
+      // columns >= NC of this sphere's Jacobian are zero, and so are the columns [NB, FIRST) of the OTHER arm of a
+      // two-arm robot: those entries of g and G are never touched (the arm-A x arm-B block of G stays a compile-time
+      // zero and takes no registers)
+      constexpr int NC = decltype(nc)::value, FIRST = decltype(nc)::first, NB = K::NB;
+      auto live = [](int k) { return !(k >= NB && k < FIRST); };
       double Jr[NC];
 #pragma unroll
       for (int k = 0; k < NC; k++)
@@ -127,9 +131,11 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
       e += r * r;
 #pragma unroll
       for (int k = 0; k < NC; k++) {
+        if (!live(k)) continue;
         gv[k] += Jr[k] * r;
 #pragma unroll
-        for (int k2 = k; k2 < NC; k2++) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
+        for (int k2 = k; k2 < NC; k2++)
+          if (live(k2)) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
       }
     };
     K::visit_spheres(
