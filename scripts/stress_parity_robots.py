@@ -11,6 +11,7 @@ from gpmp2_amd.settings import TrajOptimizerSetting
 from oracle import Oracle
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+only = int(sys.argv[2]) if len(sys.argv) > 2 else None   # run just this case (e.g. under GPMP2MI_WIDE_DENSE=1)
 eng, orc = engine.Engine(), Oracle()
 rng = np.random.default_rng(777)
 wam = g.generateArm("WAMArm")
@@ -70,6 +71,8 @@ for case in range(cases):
         init[b, :, D:] = (end - start)[None, :] / st.total_time
     z = np.zeros((B, D))
     args = (np.repeat(start[None], B, 0), z, np.repeat(end[None], B, 0), z)
+    if only is not None and case != only:       # (the random stream above is consumed either way)
+        continue
     r, s = eng.robot(model), eng.sdf(origin, cell, data)
     ro, so = orc.robot(model), orc.sdf(origin, cell, data)
     res = eng.batch_optimize(r, s, st, *args, init)
@@ -79,6 +82,10 @@ for case in range(cases):
     ok = same and dtraj < 1e-5
     bad += not ok
     worst = max(worst, dtraj)
+    if only is not None:
+        per = np.abs(res["traj"] - ref["traj"]).reshape(B, -1).max(1)
+        print("per-trajectory max|dtraj|", [float(f"{x:.1e}") for x in per], "rel final err",
+              [float(f"{abs(a / b - 1):.1e}") for a, b in zip(res["final_error"], ref["final_error"])])
     print(f"case {case:3d} {name:18s} N={N:3d} I={inter} {opt:6s} B={B:2d} iters {int(ref['iters'].min())}..{int(ref['iters'].max())} "
           f"flow {'same' if same else 'DIFF'} max|dtraj| {dtraj:.1e} {'ok' if ok else 'FAIL'}", flush=True)
 print(f"{cases - bad}/{cases} cases agree (identical iteration counts and status, trajectories < 1e-5); worst {worst:.1e}")
