@@ -376,3 +376,47 @@ def test_pr2_ragged_tree(engine, oracle):
     assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
     np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
     np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-6)
+
+
+@pytest.mark.parametrize("which", ["wam (one tile)", "mobile WAM (2x2 tiles)", "PR2 (dense blocks)"])
+def test_bad_pivot_stops_one_trajectory_only(engine, which):
+    """a trajectory whose normal equations have no Cholesky factor (here: a NaN state, so every pivot test fails) ends
+    with GPMP2MI_TRAJ_NOT_SPD -- gtsam::IndeterminantLinearSystemException in the reference -- on every solver path
+    (fused GN kernels, chip-wide levels + split tail of the 2x2-tile path, dense cyclic reduction), and the other
+    trajectories of the batch finish exactly as they do without it"""
+    from gpmp2_amd import engine as E
+    if which.startswith("wam"):
+        model, N = g.generateArm("WAMArm"), 24
+    elif which.startswith("mobile"):
+        model, N = _wide_models()["mobile WAM (dof 10)"], 20
+    else:
+        model, N = g.generateMobileArm("PR2"), 9
+    D = model.dof()
+    p = _tree_problem(model, N=N, inter=1, opt="GN")
+    if model.kind < 2:                                          # fixed-base arm: joint-space endpoints
+        p.start_conf[0, :] = 0.1
+        p.end_conf[0, :] = np.linspace(0.3, 0.9, D)
+    B = 3
+    start, end = np.repeat(p.start_conf, B, 0), np.repeat(p.end_conf, B, 0)
+    end[2, -1] += 0.2
+    init = np.zeros((B, N + 1, 2 * D))
+    for b in range(B):
+        for i in range(N + 1):
+            init[b, i, :D] = start[b] * (N - i) / N + end[b] * i / N
+        init[b, :, D:] = (end[b] - start[b])[None, :] / 3.0
+    z = np.zeros((B, D))
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    for opt in ("GN", "LM"):
+        {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM}[opt]()
+        good = engine.batch_optimize(r, s, p.setting, start, z, end, z, init)
+        assert E.TRAJ_NOT_SPD not in list(good["status"])
+        broken = init.copy()
+        broken[1, N // 2, D - 1] = np.nan
+        res = engine.batch_optimize(r, s, p.setting, start, z, end, z, broken)
+        if opt == "GN":
+            assert res["status"][1] == E.TRAJ_NOT_SPD, list(res["status"])
+        else:   # LM takes a failed factorisation as a rejected step: lambda grows to its bound, the state stays
+            assert res["status"][1] in (E.TRAJ_MAX_ITER, E.TRAJ_CONVERGED, E.TRAJ_NOT_SPD), list(res["status"])
+        for b in (0, 2):
+            assert res["status"][b] == good["status"][b] and res["iters"][b] == good["iters"][b]
+            np.testing.assert_array_equal(res["traj"][b], good["traj"][b])
