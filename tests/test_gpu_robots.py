@@ -276,10 +276,12 @@ def test_wide_dense_fallback_agrees(engine, oracle, monkeypatch):
     np.testing.assert_allclose(tiles["traj"], dense["traj"], atol=1e-7)
 
 
-def test_wide_robot_replanning(engine, oracle):
-    """fix_state / change_goal / update on a 10-dof mobile manipulator (2x2-tile blocks carry the extra priors too)"""
+@pytest.mark.parametrize("N", [10, 21])
+def test_wide_robot_replanning(engine, oracle, N):
+    """fix_state / change_goal / update on a 10-dof mobile manipulator (2x2-tile blocks carry the extra priors too);
+    total_step 21 runs the chip-wide levels and the split tail"""
     model = _wide_models()["mobile WAM (dof 10)"]
-    p = _tree_problem(model, N=10, inter=2, opt="GN")
+    p = _tree_problem(model, N=N, inter=2, opt="GN")
     D = model.dof()
     r, ro = engine.robot(p.model), oracle.robot(p.model)
     s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
