@@ -233,7 +233,7 @@ struct gpmp2mi_plan {
   size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
 };
 
-static int plan_run(gpmp2mi_plan* p, hipStream_t st);
+static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start);
 
 // linearize `traj` into record buffer `bufsel` of every (active) trajectory: the fused obstacle / GP-prior kernel,
 // then -- only for plans that carry extra factors -- the workspace / self-collision factor kernels on the support
@@ -1142,8 +1142,7 @@ int gpmp2mi_plan_optimize(gpmp2mi_plan* p, void* stream) {
   G2_CHECK(p, GPMP2MI_ERR_INVALID, "null plan");
   G2_CHECK(p->problem_set, GPMP2MI_ERR_INVALID, "call gpmp2mi_plan_set_problem first");
   hipStream_t st = (hipStream_t)stream;
-  G2_HIP(hipMemcpyAsync(p->pb.cur, p->pb.init, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
-  return plan_run(p, st);
+  return plan_run(p, st, p->pb.init);   // cur = init is part of the reset kernel
 }
 
 // Active-trajectory count of a finished pass.  The closing kernel of every pass publishes it to a pinned,
@@ -1196,12 +1195,12 @@ static int wait_pass_count(gpmp2mi_plan* p, int pass, hipStream_t st, int* count
 }
 
 // the optimizer driver: `cur` holds the starting values
-static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
+static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
   const PlanParams& P = p->hp;
   PlanBuffers& pb = p->pb;
   p->timer.reset();
   for (int k = 0; k < p->n_active_len; k++) p->h_flags[k] = -1;  // the previous run has drained (stream sync below)
-  G2_TRY(launch_plan_reset(P, pb, st));
+  G2_TRY(launch_plan_reset(P, pb, start, st));
   const int iter_cap = (P.fixed_iters > 0 ? P.fixed_iters : P.max_iter);
   if (P.opt_type == GPMP2MI_OPT_GAUSS_NEWTON && !p->generic_gn && !P.wide) {
     // ---- Gauss-Newton fast path: 3 launches per pass, step control fused into the solve kernel.
@@ -1296,8 +1295,8 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st) {
   p->optimized = true;
   return GPMP2MI_OK;
 }
-static int plan_run(gpmp2mi_plan* p, hipStream_t st) {
-  const int rc = plan_run_impl(p, st);
+static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start) {
+  const int rc = plan_run_impl(p, st, start);
   // error path: the next run resets the host flags assuming the stream has drained
   if (rc != GPMP2MI_OK) (void)hipStreamSynchronize(st);
   return rc;
@@ -1439,7 +1438,6 @@ int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // warm start: the previous estimate becomes the initial values of this run
   const double* from = p->optimized ? p->pb.result : p->pb.init;
-  G2_HIP(hipMemcpyAsync(p->pb.cur, from, p->tsz() * sizeof(double), hipMemcpyDeviceToDevice, st));
   // temporarily switch the resident parameters to `iterations` fixed Gauss-Newton steps
   PlanParams saved = p->hp;
   p->hp.opt_type = GPMP2MI_OPT_GAUSS_NEWTON;
@@ -1447,7 +1445,7 @@ int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream) {
   G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));
   const bool gg = p->generic_gn;
   p->generic_gn = false;
-  const int rc = plan_run(p, st);
+  const int rc = plan_run(p, st, from);
   p->generic_gn = gg;
   p->hp = saved;
   G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));

@@ -364,29 +364,37 @@ int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const doubl
 }
 
 
-// reset the per-trajectory optimizer state before a run: cur = init is copied by the host
-__global__ void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+// reset the optimizer state before a run and load the starting values: cur = start (no separate copy command in
+// the stream); grid-stride over the flat index ranges so that no thread writes a long serial run
+__global__ __launch_bounds__(256) void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                    const double* __restrict__ start) {
   const PlanParams& P = *pp;
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b == 0)
-    for (int k = 0; k < P.max_pass; k++) pb.n_active[k] = pb.done[k] = 0;
-  if (b >= P.B) return;
-  pb.iters[b] = 0;
-  pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
-  pb.active[b] = 1;
-  pb.phase[b] = 0;
-  pb.which[b] = 0;
-  pb.stepped[b] = 0;
-  for (int k = 0; k < SC_COUNT; k++) pb.scal[(size_t)b * SC_COUNT + k] = 0.0;
-  pb.notspd[b] = 0;
-  pb.cur_err[b] = pb.prev_err[b] = pb.last_err[b] = pb.final_err[b] = 0.0;
-  pb.lambda[b] = (P.opt_type == GPMP2MI_OPT_DOGLEG) ? P.dl_delta0 : P.lm_lambda0;
-  double* tr = pb.trace + (size_t)b * (P.max_iter + 1);
-  for (int k = 0; k <= P.max_iter; k++) tr[k] = __longlong_as_double(0x7ff8000000000000LL);
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+  const size_t B = P.B;
+  if (start) {
+    const size_t tot = B * (size_t)(P.N + 1) * P.n;
+    for (size_t k = tid; k < tot; k += nth) pb.cur[k] = start[k];
+  }
+  for (size_t k = tid; k < (size_t)P.max_pass; k += nth) pb.n_active[k] = pb.done[k] = 0;
+  for (size_t k = tid; k < B * SC_COUNT; k += nth) pb.scal[k] = 0.0;
+  for (size_t k = tid; k < B * (size_t)(P.max_iter + 1); k += nth) pb.trace[k] = __longlong_as_double(0x7ff8000000000000LL);
+  for (size_t b = tid; b < B; b += nth) {
+    pb.iters[b] = 0;
+    pb.status[b] = GPMP2MI_TRAJ_MAX_ITER;
+    pb.active[b] = 1;
+    pb.phase[b] = 0;
+    pb.which[b] = 0;
+    pb.stepped[b] = 0;
+    pb.notspd[b] = 0;
+    pb.cur_err[b] = pb.prev_err[b] = pb.last_err[b] = pb.final_err[b] = 0.0;
+    pb.lambda[b] = (P.opt_type == GPMP2MI_OPT_DOGLEG) ? P.dl_delta0 : P.lm_lambda0;
+  }
 }
 
-int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
-  k_plan_reset<<<dim3((hp.B + 63) / 64), dim3(64), 0, st>>>(pb.params, pb);
+int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, const double* start, hipStream_t st) {
+  const size_t tot = (size_t)hp.B * (hp.N + 1) * hp.n;
+  const int blocks = (int)std::min<size_t>(1024, std::max<size_t>(1, (tot + 1023) / 1024));
+  k_plan_reset<<<dim3(blocks), dim3(256), 0, st>>>(pb.params, pb, start);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
