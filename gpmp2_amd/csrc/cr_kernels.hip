@@ -363,6 +363,7 @@ __device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, c
 }
 
 // =============================================================================== GN step (CR)
+constexpr int FIN_BLOCKS = 8;   // blocks per workgroup of k_finish_step / k_finish_trial (levels 4, 2, 1 run there)
 #ifndef G2_CR_WAVES
 #define G2_CR_WAVES 16
 #endif
@@ -582,12 +583,15 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
   }
 
   if (P.split_back) {
-    // the two widest back-substitution levels (75 of the 101 blocks) and the retract run chip-wide in
-    // k_finish_step; this kernel only solves the blocks that are multiples of 4 and hands them over
-    cr_backward<n>(pb, b, N, tid, xs, 4);
+    // the three widest back-substitution levels (88 of the 101 blocks) and the retract run chip-wide in
+    // k_finish_step; this kernel only solves the blocks that are multiples of 8 and hands them over
+    cr_backward<n>(pb, b, N, tid, xs, FIN_BLOCKS);
     G2_STAMP(3);
     double* xg = pb.xg + (size_t)b * (N + 1) * 16;
-    for (int k = tid; k < (N / 4 + 1) * 16; k += blockDim.x) xg[(size_t)(k >> 4) * 64 + (k & 15)] = xs[(k >> 4) * 64 + (k & 15)];
+    for (int k = tid; k < (N / FIN_BLOCKS + 1) * 16; k += blockDim.x) {
+      const size_t o = (size_t)(k >> 4) * FIN_BLOCKS * 16 + (k & 15);
+      xg[o] = xs[o];
+    }
     G2_STAMP(4);
     if (tid == 0) {
       pb.stepped[b] = pass + 1;
@@ -622,58 +626,82 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_gn_step_cr(const PlanParams* 
   if (threadIdx.x == 0) publish_pass_count(pb, pass);
 }
 
-// Chip-wide tail of a Gauss-Newton pass (split path): one workgroup of 4 wavefronts per (trajectory, blocks
-// 4q .. 4q+3).  Block 4q+2 is back-substituted from x_{4q}, x_{4q+4} (level 2), then the odd blocks from
-// their neighbours (level 1), then every wavefront retracts its own state: last = cur; cur = cur (+) x.
+// Chip-wide tail of a Gauss-Newton pass (split path): one workgroup of 8 wavefronts per (trajectory, blocks
+// 8q .. 8q+7).  Block 8q+4 is back-substituted from x_{8q}, x_{8q+8} (level 4), then 8q+2 / 8q+6 (level 2), then the
+// odd blocks (level 1); every wavefront then retracts its own state: last = cur; cur = cur (+) x.
+// (FIN_BLOCKS is declared next to CR_WAVES: the step kernels stop their back-substitution at the multiples of it.)
 template <int D>
-__global__ __launch_bounds__(256) void k_finish_step(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass) {
+struct FinishGroup {
+  static constexpr int n = 2 * D;
+  Tile Wl, Wr, V;
+  int b, q, wv, lane, c, g, i, N;
+  bool live;
+  // loads of the wavefront's factor tiles are requested right away, so they are in flight while the levels above
+  // are being solved
+  __device__ __forceinline__ FinishGroup(const PlanBuffers& pb, int N_, int b_, int q_, double (*xl_)[16])
+      : b(b_), q(q_), N(N_) {
+    wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    lane = threadIdx.x & 63;
+    c = lane & 15;
+    g = lane >> 4;
+    i = FIN_BLOCKS * q + wv;
+    live = i <= N;
+    const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+    const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+    Wl = Wr = V = tile_zero();
+    if (live && wv != 0) {
+      const double* f = fac + (size_t)i * 3 * TILE_DBL;
+      Wl = tile_load_rows<n>(f, lane);
+      Wr = tile_load_rows<n>(f + TILE_DBL, lane);
+      V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
+    }
+    if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(FIN_BLOCKS * q) * 16 + lane];
+    if (wv == 1 && lane < 16)
+      xl_[FIN_BLOCKS][lane] = (FIN_BLOCKS * q + FIN_BLOCKS <= N) ? xg[(size_t)(FIN_BLOCKS * q + FIN_BLOCKS) * 16 + lane] : 0.0;
+  }
+  __device__ __forceinline__ void solve(int h, double (*xl_)[16]) const {
+    const int jl = i - h, jr = i + h;
+    const double xl = (jl >= 0) ? xl_[jl - FIN_BLOCKS * q][c] : 0.0;
+    const double xr = (jr <= N) ? xl_[jr - FIN_BLOCKS * q][c] : 0.0;
+    const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+    if (g == 0) xl_[wv][c] = (c < n) ? x : 0.0;
+  }
+  // levels 4, 2, 1 (every wavefront of the workgroup must call this)
+  __device__ __forceinline__ void solve_all(double (*xl_)[16]) const {
+    __syncthreads();
+    if (wv == 4 && live) solve(4, xl_);
+    __syncthreads();
+    if ((wv == 2 || wv == 6) && live) solve(2, xl_);
+    __syncthreads();
+    if ((wv & 1) && live) solve(1, xl_);
+    __syncthreads();
+  }
+};
+
+template <int D>
+__global__ __launch_bounds__(64 * FIN_BLOCKS) void k_finish_step(const PlanParams* __restrict__ pp, PlanBuffers pb, int pass) {
   constexpr int n = 2 * D;
   const PlanParams& P = *pp;
   const int N = P.N;
-  const int groups = (N + 4) / 4;
+  const int groups = (N + FIN_BLOCKS) / FIN_BLOCKS;
   const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
   if (pb.stepped[b] != pass + 1) return;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int i = 4 * q + wv;
-  const bool live = i <= N;
-  __shared__ double xl_[4][16];
-  const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
-  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
-  // every wavefront that has a block to solve (4q+2 at level 2, the odd ones at level 1) requests its three factor
-  // tiles and its old state right away, so the level-1 loads are in flight while level 2 is being solved
-  const bool has_block = live && wv != 0;
-  Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
-  if (has_block) {
-    const double* f = fac + (size_t)i * 3 * TILE_DBL;
-    Wl = tile_load_rows<n>(f, lane);
-    Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-    V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
-  }
-  auto solve = [&](int j, int h) {
-    const int jl = j - h, jr = j + h;
-    auto xof = [&](int m) { return (m & 3) ? xl_[m & 3][c] : xg[(size_t)m * 16 + c]; };
-    const double xl = (jl >= 0) ? xof(jl) : 0.0;
-    const double xr = (jr <= N) ? xof(jr) : 0.0;
-    const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
-    if (g == 0) xl_[j & 3][c] = (c < n) ? x : 0.0;
-  };
-  if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(4 * q) * 16 + lane];
-  if (wv == 2 && live) solve(i, 2);
-  __syncthreads();
-  if ((wv & 1) && live) solve(i, 1);
-  __syncthreads();
-  if (!live || lane >= n) return;
+  __shared__ double xl_[FIN_BLOCKS + 1][16];
+  const FinishGroup<D> fg(pb, N, b, q, xl_);
+  fg.solve_all(xl_);
+  const int lane = fg.lane, i = fg.i;
+  if (!fg.live || lane >= n) return;
   const size_t k = ((size_t)b * (N + 1) + i) * n + lane;
   const double* zs = pb.cur + ((size_t)b * (N + 1) + i) * n;
   const double zold = zs[lane];
-  const double znew = (lane < D) ? retract_coord(P.lie != 0, lane, zs, xl_[wv]) : zold + xl_[wv][lane];
+  const double znew = (lane < D) ? retract_coord(P.lie != 0, lane, zs, xl_[fg.wv]) : zold + xl_[fg.wv][lane];
   pb.last[k] = zold;
   __builtin_amdgcn_wave_barrier();  // every lane has read the old state of this block before any lane overwrites it
   pb.cur[k] = znew;
 }
 
 int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hipStream_t st) {
-  const dim3 grid(hp.B * ((hp.N + 4) / 4)), block(256);
+  const dim3 grid(hp.B * ((hp.N + FIN_BLOCKS) / FIN_BLOCKS)), block(64 * FIN_BLOCKS);
   switch (hp.D) {
 #define G2_FIN_CASE(DD) \
   case DD: k_finish_step<DD><<<grid, block, 0, st>>>(pb.params, pb, pass); break;
@@ -691,43 +719,20 @@ int launch_finish_step(const PlanParams& hp, const PlanBuffers& pb, int pass, hi
 // `delta`, the trial point cur (+) delta to `trial` (cur stays), and every workgroup leaves its share of g.delta,
 // |delta|^2, |g|^2 in spart for the step control (k_decide sums them in group order).
 template <int D>
-__global__ __launch_bounds__(256) void k_finish_trial(const PlanParams* __restrict__ pp, PlanBuffers pb) {
+__global__ __launch_bounds__(64 * FIN_BLOCKS) void k_finish_trial(const PlanParams* __restrict__ pp, PlanBuffers pb) {
   constexpr int n = 2 * D;
   const PlanParams& P = *pp;
   const int N = P.N;
-  const int groups = (N + 4) / 4;
+  const int groups = (N + FIN_BLOCKS) / FIN_BLOCKS;
   const int b = blockIdx.x / groups, q = blockIdx.x - b * groups;
   if (!pb.active[b] || pb.stepped[b] != 1) return;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int i = 4 * q + wv;
-  const bool live = i <= N;
-  __shared__ double xl_[4][16];
-  __shared__ double psum[4][3];
-  const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
-  const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
-  const bool has_block = live && wv != 0;
-  Tile Wl = tile_zero(), Wr = tile_zero(), V = tile_zero();
-  if (has_block) {
-    const double* f = fac + (size_t)i * 3 * TILE_DBL;
-    Wl = tile_load_rows<n>(f, lane);
-    Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-    V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
-  }
-  auto solve = [&](int j, int h) {
-    const int jl = j - h, jr = j + h;
-    auto xof = [&](int m) { return (m & 3) ? xl_[m & 3][c] : xg[(size_t)m * 16 + c]; };
-    const double xl = (jl >= 0) ? xof(jl) : 0.0;
-    const double xr = (jr <= N) ? xof(jr) : 0.0;
-    const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
-    if (g == 0) xl_[j & 3][c] = (c < n) ? x : 0.0;
-  };
-  if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(4 * q) * 16 + lane];
-  if (wv == 2 && live) solve(i, 2);
-  __syncthreads();
-  if ((wv & 1) && live) solve(i, 1);
-  __syncthreads();
+  __shared__ double xl_[FIN_BLOCKS + 1][16];
+  __shared__ double psum[FIN_BLOCKS][3];
+  const FinishGroup<D> fg(pb, N, b, q, xl_);
+  fg.solve_all(xl_);
+  const int lane = fg.lane, i = fg.i, wv = fg.wv;
   double gd = 0.0, dd = 0.0, gg = 0.0;
-  if (live && lane < n) {
+  if (fg.live && lane < n) {
     const size_t k = ((size_t)b * (N + 1) + i) * n + lane;
     const double* zs = pb.cur + ((size_t)b * (N + 1) + i) * n;
     const double x = xl_[wv][lane], gk = pb.gvec[((size_t)b * (N + 1) + i) * 16 + lane];
@@ -748,12 +753,14 @@ __global__ __launch_bounds__(256) void k_finish_trial(const PlanParams* __restri
   __syncthreads();
   if (threadIdx.x < 3) {
     const int t = threadIdx.x;
-    pb.spart[((size_t)b * groups + q) * 3 + t] = ((psum[0][t] + psum[1][t]) + psum[2][t]) + psum[3][t];
+    double a = 0.0;
+    for (int w = 0; w < FIN_BLOCKS; w++) a += psum[w][t];
+    pb.spart[((size_t)b * groups + q) * 3 + t] = a;
   }
 }
 
 int launch_finish_trial(const PlanParams& hp, const PlanBuffers& pb, hipStream_t st) {
-  const dim3 grid(hp.B * ((hp.N + 4) / 4)), block(256);
+  const dim3 grid(hp.B * ((hp.N + FIN_BLOCKS) / FIN_BLOCKS)), block(64 * FIN_BLOCKS);
   switch (hp.D) {
 #define G2_FINT_CASE(DD) \
   case DD: k_finish_trial<DD><<<grid, block, 0, st>>>(pb.params, pb); break;
@@ -841,11 +848,14 @@ __global__ __launch_bounds__(64 * CR_WAVES) void k_solve_step(const PlanParams* 
       return;
     }
     if (P.split_back && !dogleg) {
-      // LM / GN: as on the Gauss-Newton fast path only the blocks that are multiples of 4 are back-substituted
-      // here; levels 2, 1, the step, the trial point and the step-control sums follow chip-wide in k_finish_trial
-      cr_backward<n>(pb, b, N, tid, xs, 4);
+      // LM / GN: as on the Gauss-Newton fast path only the blocks that are multiples of 8 are back-substituted
+      // here; levels 4, 2, 1, the step, the trial point and the step-control sums follow chip-wide in k_finish_trial
+      cr_backward<n>(pb, b, N, tid, xs, FIN_BLOCKS);
       double* xg = pb.xg + (size_t)b * (N + 1) * 16;
-      for (int k = tid; k < (N / 4 + 1) * 16; k += blockDim.x) xg[(size_t)(k >> 4) * 64 + (k & 15)] = xs[(k >> 4) * 64 + (k & 15)];
+      for (int k = tid; k < (N / FIN_BLOCKS + 1) * 16; k += blockDim.x) {
+        const size_t o = (size_t)(k >> 4) * FIN_BLOCKS * 16 + (k & 15);
+        xg[o] = xs[o];
+      }
       if (tid == 0) pb.stepped[b] = 1;
       return;
     }
