@@ -69,7 +69,8 @@ def test_every_block_is_eliminated_once_and_in_order(first_level):
 
 
 def test_wide_split_tail_groups_cover_every_block():
-    """k_finish_trial_wide: groups of 8 blocks; the multiples of 8 come from the solve kernel (levels >= 8), block
+    """k_finish_step / k_finish_trial / k_finish_trial_wide: groups of 8 blocks; the multiples of 8 come from the solve
+    kernel (levels >= 8), block
     8q+4 needs x_{8q}, x_{8q+8}, then 8q+2 / 8q+6, then the odd ones -- the neighbours always sit in slots 0..8"""
     for N in range(16, 260):
         groups = (N + 8) // 8
