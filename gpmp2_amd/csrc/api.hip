@@ -988,7 +988,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
   G2_TRY(plan_alloc(p.get(), &pb.spart, (size_t)B * ((P.N + 4) / 4) * 3));
   G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * (wide ? 32 : 16)));
-  if (wide) {
+  if (dense_path) {   // dense normal equations + the factors of the dense cyclic reduction
     G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
     G2_TRY(plan_alloc(p.get(), &pb.wHo, (size_t)B * P.N * P.n * P.n));
     G2_TRY(plan_alloc(p.get(), &pb.wg, (size_t)B * (P.N + 1) * P.n));
@@ -1030,8 +1030,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   {
     const char* e = getenv("GPMP2MI_GENERIC_GN");
     p->generic_gn = e && e[0] == '1';
-    const char* wd = getenv("GPMP2MI_WIDE_DENSE");
-    p->wide_dense = (wd && wd[0] == '1') || dense_only;
+    p->wide_dense = dense_path;   // GPMP2MI_WIDE_DENSE=1 (read above) or dof > 11
     const int cap = std::max(P.fixed_iters, P.max_iter);   // plan_update may run any iterations <= max_iter
     // passes: GN one per iteration (+1); LM up to ~5 lambda retries per iterate; Dogleg up to ~16 halvings
     const int mult = P.opt_type == GPMP2MI_OPT_LM ? 6 : P.opt_type == GPMP2MI_OPT_DOGLEG ? 18 : 1;
