@@ -1210,8 +1210,14 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
     for (int pass = 0; pass < max_pass; pass++) {
       p->timer.begin("linearize", st);
       G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
-      p->timer.begin("assemble", st);
-      G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+      if (P.fixed_iters > 0 && pass == P.fixed_iters) {
+        // closing pass of a fixed-iteration run: nothing is solved any more, only the error of the final values
+        p->timer.begin("final_error", st);
+        G2_TRY(launch_error_parts(P, pb, pb.cur, 0, pb.active, st));
+      } else {
+        p->timer.begin("assemble", st);
+        G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+      }
       p->timer.begin("gn_step_cr", st);
       G2_TRY(launch_gn_step_cr(P, pb, pass, st));
       if (P.split_back) {

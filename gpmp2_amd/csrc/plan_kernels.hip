@@ -364,6 +364,28 @@ int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const doubl
 }
 
 
+// The closing pass of a run with a fixed number of iterations only evaluates the error of the final values (every
+// trajectory stops in the step kernel before it factorises anything): instead of k_assemble, which would build and
+// eliminate all blocks for nothing, this kernel leaves the graph error of each active trajectory where the step kernel
+// looks for it -- the whole sum in the share of block 0, zeros in the others.
+__global__ __launch_bounds__(64) void k_error_parts(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                     const double* __restrict__ traj, int bufsel,
+                                                     const int* __restrict__ active) {
+  const PlanParams& P = *pp;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (active && !active[b]) return;
+  const double e = total_error(P, pb, b, traj + (size_t)b * (P.N + 1) * P.n, rec_of(pb, pb.which[b], bufsel),
+                               gpu_of(pb, pb.which[b], bufsel), lane);
+  for (int i = lane; i <= P.N; i += 64) pb.epart[(size_t)b * P.Npad + i] = (i == 0) ? e : 0.0;
+}
+
+int launch_error_parts(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
+                       hipStream_t st) {
+  k_error_parts<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, traj, bufsel, active);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 // reset the optimizer state before a run and load the starting values: cur = start (no separate copy command in
 // the stream); grid-stride over the flat index ranges so that no thread writes a long serial run
 __global__ __launch_bounds__(256) void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb,
