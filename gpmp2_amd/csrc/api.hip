@@ -1447,13 +1447,16 @@ int gpmp2mi_plan_update(gpmp2mi_plan* p, int iterations, void* stream) {
   PlanParams saved = p->hp;
   p->hp.opt_type = GPMP2MI_OPT_GAUSS_NEWTON;
   p->hp.fixed_iters = iterations;
-  G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));
+  if (const int rc0 = launch_set_mode(p->pb, p->hp.opt_type, p->hp.fixed_iters, st)) {
+    p->hp = saved;
+    return rc0;
+  }
   const bool gg = p->generic_gn;
   p->generic_gn = false;
   const int rc = plan_run(p, st, from);
   p->generic_gn = gg;
   p->hp = saved;
-  G2_HIP(hipMemcpyAsync(p->pb.params, &p->hp, sizeof(PlanParams), hipMemcpyHostToDevice, st));
+  G2_TRY(launch_set_mode(p->pb, p->hp.opt_type, p->hp.fixed_iters, st));
   G2_HIP(hipStreamSynchronize(st));
   return rc;
 }

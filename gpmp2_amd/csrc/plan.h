@@ -144,6 +144,7 @@ int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev
                      const int* active, hipStream_t st);
 int launch_extra_accumulate(const PlanParams& hp, const PlanBuffers& pb, const PlanExtras& ex, int L, int S, int bufsel,
                             const int* active, hipStream_t st);
+int launch_set_mode(const PlanBuffers& pb, int opt_type, int fixed_iters, hipStream_t st);
 int launch_error_parts(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
                        hipStream_t st);
 int launch_plan_reset(const PlanParams& hp, const PlanBuffers& pb, const double* start, hipStream_t st);

@@ -386,6 +386,18 @@ int launch_error_parts(const PlanParams& hp, const PlanBuffers& pb, const double
   return GPMP2MI_OK;
 }
 
+// gpmp2mi_plan_update switches the resident parameter block to `iterations` fixed Gauss-Newton steps and back: two
+// words, written in stream order by this kernel instead of re-uploading the block from pageable host memory twice
+__global__ void k_set_mode(PlanParams* pp, int opt_type, int fixed_iters) {
+  pp->opt_type = opt_type;
+  pp->fixed_iters = fixed_iters;
+}
+int launch_set_mode(const PlanBuffers& pb, int opt_type, int fixed_iters, hipStream_t st) {
+  k_set_mode<<<dim3(1), dim3(1), 0, st>>>(pb.params, opt_type, fixed_iters);
+  G2_HIP(hipGetLastError());
+  return GPMP2MI_OK;
+}
+
 // reset the optimizer state before a run and load the starting values: cur = start (no separate copy command in
 // the stream); grid-stride over the flat index ranges so that no thread writes a long serial run
 __global__ __launch_bounds__(256) void k_plan_reset(const PlanParams* __restrict__ pp, PlanBuffers pb,
