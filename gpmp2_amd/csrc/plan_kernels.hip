@@ -368,20 +368,25 @@ int launch_error_reduce(const PlanParams& hp, const PlanBuffers& pb, const doubl
 // trajectory stops in the step kernel before it factorises anything): instead of k_assemble, which would build and
 // eliminate all blocks for nothing, this kernel leaves the graph error of each active trajectory where the step kernel
 // looks for it -- the whole sum in the share of block 0, zeros in the others.
-__global__ __launch_bounds__(64) void k_error_parts(const PlanParams* __restrict__ pp, PlanBuffers pb,
-                                                     const double* __restrict__ traj, int bufsel,
-                                                     const int* __restrict__ active) {
+__global__ __launch_bounds__(256) void k_error_parts(const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                      const double* __restrict__ traj, int bufsel,
+                                                      const int* __restrict__ active) {
   const PlanParams& P = *pp;
-  const int b = blockIdx.x, lane = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x;
   if (active && !active[b]) return;
-  const double e = total_error(P, pb, b, traj + (size_t)b * (P.N + 1) * P.n, rec_of(pb, pb.which[b], bufsel),
-                               gpu_of(pb, pb.which[b], bufsel), lane);
-  for (int i = lane; i <= P.N; i += 64) pb.epart[(size_t)b * P.Npad + i] = (i == 0) ? e : 0.0;
+  __shared__ double red[4];
+  const double part = total_error_partial(P, pb, b, traj + (size_t)b * (P.N + 1) * P.n, rec_of(pb, pb.which[b], bufsel),
+                                          gpu_of(pb, pb.which[b], bufsel), tid, 256);
+  const double ws = wave_sum(part);
+  if ((tid & 63) == 0) red[tid >> 6] = ws;
+  __syncthreads();
+  const double e = 0.5 * (((red[0] + red[1]) + red[2]) + red[3]);   // the fixed-order sum of k_decide
+  for (int i = tid; i <= P.N; i += 256) pb.epart[(size_t)b * P.Npad + i] = (i == 0) ? e : 0.0;
 }
 
 int launch_error_parts(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
                        hipStream_t st) {
-  k_error_parts<<<dim3(hp.B), dim3(64), 0, st>>>(pb.params, pb, traj, bufsel, active);
+  k_error_parts<<<dim3(hp.B), dim3(256), 0, st>>>(pb.params, pb, traj, bufsel, active);
   G2_HIP(hipGetLastError());
   return GPMP2MI_OK;
 }
