@@ -8,6 +8,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <fstream>
 #include <vector>
@@ -214,6 +215,13 @@ struct KernelTimer {
   }
 };
 
+// a pinned, device-mapped int array from the pool of flags_acquire / flags_release
+struct FlagBuf {
+  int* host = nullptr;
+  int* dev = nullptr;
+  int cap = 0;
+};
+
 struct gpmp2mi_plan {
   const gpmp2mi_robot* robot = nullptr;
   const gpmp2mi_sdf* sdf = nullptr;
@@ -222,6 +230,7 @@ struct gpmp2mi_plan {
   std::vector<void*> allocs;   // arena chunks (plan_alloc)
   char* arena_cur = nullptr;   // bump pointer into the newest chunk
   size_t arena_left = 0;
+  FlagBuf flagbuf;
   int* h_flags = nullptr;    // pinned + device-mapped [n_active_len]: per-pass active count, -1 = not yet known
   KernelTimer timer;
   bool wide_dense = false;   // GPMP2MI_WIDE_DENSE=1: 8..11-dof plans through the dense block solver (A/B, fallback)
@@ -258,6 +267,34 @@ static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const
     G2_TRY(launch_self_collision(ex.n_sc, S, D, M, ex.sc_data, ex.radius, ex.cen, ex.Jc, ex.sc_err, ex.sc_H, st));
   }
   return launch_extra_accumulate(P, p->pb, ex, L, S, bufsel, active, st);
+}
+
+// Host-mapped pass-flag arrays are recycled across plans: pinning and unpinning host memory costs more than the
+// whole solve of a small plan (one-shot gpmp2mi_batch_optimize calls create and destroy a plan each time).
+static std::mutex g_flag_mu;
+static std::vector<FlagBuf> g_flag_pool;
+static int flags_acquire(int need, FlagBuf* out) {
+  {
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    for (size_t k = 0; k < g_flag_pool.size(); k++)
+      if (g_flag_pool[k].cap >= need) {
+        *out = g_flag_pool[k];
+        g_flag_pool.erase(g_flag_pool.begin() + k);
+        return GPMP2MI_OK;
+      }
+  }
+  FlagBuf f;
+  f.cap = std::max(need, 1024);
+  G2_HIP(hipHostMalloc((void**)&f.host, (size_t)f.cap * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  G2_HIP(hipHostGetDevicePointer((void**)&f.dev, f.host, 0));
+  *out = f;
+  return GPMP2MI_OK;
+}
+static void flags_release(const FlagBuf& f) {
+  if (!f.host) return;
+  std::lock_guard<std::mutex> lk(g_flag_mu);
+  if (g_flag_pool.size() < 16) g_flag_pool.push_back(f);
+  else (void)hipHostFree(f.host);
 }
 
 // Plan buffers come out of a few zero-filled arena chunks instead of one hipMalloc + hipMemset + hipFree each (a plan
@@ -1113,8 +1150,9 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.n_active, p->n_active_len));
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
   G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
-  G2_HIP(hipHostMalloc((void**)&p->h_flags, p->n_active_len * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
-  G2_HIP(hipHostGetDevicePointer((void**)&pb.host_flags, p->h_flags, 0));
+  G2_TRY(flags_acquire(p->n_active_len, &p->flagbuf));
+  p->h_flags = p->flagbuf.host;
+  pb.host_flags = p->flagbuf.dev;
   G2_TRY(plan_alloc(p.get(), &pb.done, p->n_active_len));
   *out = p.release();
   return GPMP2MI_OK;
@@ -1123,7 +1161,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
 void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
   if (!p) return;
   for (void* q : p->allocs) (void)hipFree(q);
-  if (p->h_flags) (void)hipHostFree(p->h_flags);
+  flags_release(p->flagbuf);   // (the hipFree calls above have drained the device: nothing writes the flags any more)
   delete p;
 }
 
