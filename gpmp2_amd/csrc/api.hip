@@ -228,6 +228,7 @@ struct gpmp2mi_plan {
   PlanParams hp;
   PlanBuffers pb;
   std::vector<void*> allocs;   // arena chunks (plan_alloc)
+  std::vector<size_t> alloc_bytes;
   char* arena_cur = nullptr;   // bump pointer into the newest chunk
   size_t arena_left = 0;
   FlagBuf flagbuf;
@@ -299,20 +300,44 @@ static void flags_release(const FlagBuf& f) {
 
 // Plan buffers come out of a few zero-filled arena chunks instead of one hipMalloc + hipMemset + hipFree each (a plan
 // has about 65 of them: 0.6 ms of a one-shot gpmp2mi_batch_optimize call was allocation and release).
+// standard-size chunks are recycled as well (zero-filled again on reuse); larger ones go back to the driver
+constexpr size_t ARENA_CHUNK = (size_t)8 << 20;
+static std::vector<void*> g_chunk_pool;   // guarded by g_flag_mu
+static void* chunk_acquire() {
+  std::lock_guard<std::mutex> lk(g_flag_mu);
+  if (g_chunk_pool.empty()) return nullptr;
+  void* q = g_chunk_pool.back();
+  g_chunk_pool.pop_back();
+  return q;
+}
+static void chunk_release(void* q) {
+  {
+    std::lock_guard<std::mutex> lk(g_flag_mu);
+    if (g_chunk_pool.size() < 8) {
+      g_chunk_pool.push_back(q);
+      return;
+    }
+  }
+  (void)hipFree(q);
+}
+
 template <class T>
 static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
-  constexpr size_t ALIGN = 256, CHUNK = (size_t)8 << 20;
+  constexpr size_t ALIGN = 256, CHUNK = ARENA_CHUNK;
   const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + ALIGN - 1) / ALIGN * ALIGN;
   if (bytes > p->arena_left) {
     const size_t chunk = std::max(bytes, CHUNK);
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, chunk);
-    if (e != hipSuccess) {
-      set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
-      return GPMP2MI_ERR_ALLOC;
+    void* q = (chunk == CHUNK) ? chunk_acquire() : nullptr;
+    if (!q) {
+      hipError_t e = hipMalloc(&q, chunk);
+      if (e != hipSuccess) {
+        set_error(std::string("hipMalloc: ") + hipGetErrorString(e));
+        return GPMP2MI_ERR_ALLOC;
+      }
     }
     (void)hipMemset(q, 0, chunk);
     p->allocs.push_back(q);
+    p->alloc_bytes.push_back(chunk);
     p->arena_cur = (char*)q;
     p->arena_left = chunk;
   }
@@ -1160,8 +1185,12 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
 
 void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
   if (!p) return;
-  for (void* q : p->allocs) (void)hipFree(q);
-  flags_release(p->flagbuf);   // (the hipFree calls above have drained the device: nothing writes the flags any more)
+  (void)hipDeviceSynchronize();   // nothing of this plan is in flight any more: its chunks and flags can be reused
+  for (size_t k = 0; k < p->allocs.size(); k++) {
+    if (p->alloc_bytes[k] == ARENA_CHUNK) chunk_release(p->allocs[k]);
+    else (void)hipFree(p->allocs[k]);
+  }
+  flags_release(p->flagbuf);
   delete p;
 }
 
