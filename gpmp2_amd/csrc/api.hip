@@ -11,6 +11,7 @@
 #include <mutex>
 #include <numeric>
 #include <fstream>
+#include <utility>
 #include <vector>
 
 #include "common.h"
@@ -220,6 +221,7 @@ struct FlagBuf {
   int* host = nullptr;
   int* dev = nullptr;
   int cap = 0;
+  int device = -1;   // pooled buffers are reused on the device they were mapped / allocated for only
 };
 
 struct gpmp2mi_plan {
@@ -277,14 +279,17 @@ static std::vector<FlagBuf> g_flag_pool;
 static int flags_acquire(int need, FlagBuf* out) {
   {
     std::lock_guard<std::mutex> lk(g_flag_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
     for (size_t k = 0; k < g_flag_pool.size(); k++)
-      if (g_flag_pool[k].cap >= need) {
+      if (g_flag_pool[k].cap >= need && g_flag_pool[k].device == cur) {
         *out = g_flag_pool[k];
         g_flag_pool.erase(g_flag_pool.begin() + k);
         return GPMP2MI_OK;
       }
   }
   FlagBuf f;
+  (void)hipGetDevice(&f.device);
   f.cap = std::max(need, 1024);
   G2_HIP(hipHostMalloc((void**)&f.host, (size_t)f.cap * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
   G2_HIP(hipHostGetDevicePointer((void**)&f.dev, f.host, 0));
@@ -302,19 +307,24 @@ static void flags_release(const FlagBuf& f) {
 // has about 65 of them: 0.6 ms of a one-shot gpmp2mi_batch_optimize call was allocation and release).
 // standard-size chunks are recycled as well (zero-filled again on reuse); larger ones go back to the driver
 constexpr size_t ARENA_CHUNK = (size_t)8 << 20;
-static std::vector<void*> g_chunk_pool;   // guarded by g_flag_mu
+static std::vector<std::pair<void*, int>> g_chunk_pool;   // (chunk, device); guarded by g_flag_mu
 static void* chunk_acquire() {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
   std::lock_guard<std::mutex> lk(g_flag_mu);
-  if (g_chunk_pool.empty()) return nullptr;
-  void* q = g_chunk_pool.back();
-  g_chunk_pool.pop_back();
-  return q;
+  for (size_t k = 0; k < g_chunk_pool.size(); k++)
+    if (g_chunk_pool[k].second == cur) {
+      void* q = g_chunk_pool[k].first;
+      g_chunk_pool.erase(g_chunk_pool.begin() + k);
+      return q;
+    }
+  return nullptr;
 }
-static void chunk_release(void* q) {
+static void chunk_release(void* q, int device) {
   {
     std::lock_guard<std::mutex> lk(g_flag_mu);
     if (g_chunk_pool.size() < 8) {
-      g_chunk_pool.push_back(q);
+      g_chunk_pool.push_back({q, device});
       return;
     }
   }
@@ -1187,7 +1197,7 @@ void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
   if (!p) return;
   (void)hipDeviceSynchronize();   // nothing of this plan is in flight any more: its chunks and flags can be reused
   for (size_t k = 0; k < p->allocs.size(); k++) {
-    if (p->alloc_bytes[k] == ARENA_CHUNK) chunk_release(p->allocs[k]);
+    if (p->alloc_bytes[k] == ARENA_CHUNK) chunk_release(p->allocs[k], p->flagbuf.device);
     else (void)hipFree(p->allocs[k]);
   }
   flags_release(p->flagbuf);
