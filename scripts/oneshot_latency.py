@@ -18,3 +18,13 @@ for k in range(4):
     t0 = time.perf_counter()
     pl.set_problem(p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init); pl.optimize(); r = pl.result()
     print("resident plan call %d: %.2f ms  iters %s" % (k, 1e3 * (time.perf_counter() - t0), r["iters"]))
+# the three parts of a resident call
+import numpy as np
+ts = np.zeros((20, 3))
+for k in range(20):
+    t0 = time.perf_counter(); pl.set_problem(p.start_conf, p.start_vel, p.end_conf, p.end_vel, p.init)
+    t1 = time.perf_counter(); pl.optimize()
+    t2 = time.perf_counter(); r = pl.result()
+    t3 = time.perf_counter()
+    ts[k] = [t1 - t0, t2 - t1, t3 - t2]
+print("set_problem / optimize / result (median, ms):", [round(float(x), 3) for x in np.median(ts[5:], 0) * 1e3])
