@@ -2,6 +2,7 @@
 // precomputation (GP matrices, whitening weights), marshalling and the optimizer driver loop.
 // There is deliberately no CPU compute path in this file: every entry point launches kernels.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -224,54 +225,6 @@ struct FlagBuf {
   int device = -1;   // pooled buffers are reused on the device they were mapped / allocated for only
 };
 
-struct gpmp2mi_plan {
-  const gpmp2mi_robot* robot = nullptr;
-  const gpmp2mi_sdf* sdf = nullptr;
-  PlanParams hp;
-  PlanBuffers pb;
-  std::vector<void*> allocs;   // arena chunks (plan_alloc)
-  std::vector<size_t> alloc_bytes;
-  char* arena_cur = nullptr;   // bump pointer into the newest chunk
-  size_t arena_left = 0;
-  FlagBuf flagbuf;
-  int* h_flags = nullptr;    // pinned + device-mapped [n_active_len]: per-pass active count, -1 = not yet known
-  KernelTimer timer;
-  bool wide_dense = false;   // GPMP2MI_WIDE_DENSE=1: 8..11-dof plans through the dense block solver (A/B, fallback)
-  bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
-  int n_active_len = 0;
-  std::vector<int> h_xp_n;   // host mirror of the extra-prior counts
-  PlanExtras ex;             // extra factors carried as data (host copy of the specs + device workspace)
-  bool has_extras = false;
-  bool problem_set = false;
-  bool optimized = false;
-  size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
-};
-
-static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start);
-
-// linearize `traj` into record buffer `bufsel` of every (active) trajectory: the fused obstacle / GP-prior kernel,
-// then -- only for plans that carry extra factors -- the workspace / self-collision factor kernels on the support
-// states and their accumulation into the unary records
-static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st) {
-  const PlanParams& P = p->hp;
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st));
-  if (!p->has_extras) return GPMP2MI_OK;
-  const PlanExtras& ex = p->ex;
-  const RobotDev& h = p->robot->h;
-  const int M = P.B * (P.N + 1), D = P.D, L = h.nr_links, S = h.nr_spheres;
-  if (ex.n_ws > 0) {
-    G2_TRY(launch_fk(h, p->robot->d, M, traj, ex.poses, ex.Jp, st, 2 * D));
-    for (int f = 0; f < ex.n_ws; f++)
-      G2_TRY(launch_workspace_prior(ex.ws_mode[f], ex.ws_link[f], L, D, M, ex.des + 16 * f, ex.poses, ex.Jp,
-                                    ex.ws_err + (size_t)f * M * 6, ex.ws_H + (size_t)f * M * 6 * D, st));
-  }
-  if (ex.n_sc > 0) {
-    G2_TRY(launch_sphere_centers(h, p->robot->d, M, traj, ex.cen, ex.Jc, st, 2 * D));
-    G2_TRY(launch_self_collision(ex.n_sc, S, D, M, ex.sc_data, ex.radius, ex.cen, ex.Jc, ex.sc_err, ex.sc_H, st));
-  }
-  return launch_extra_accumulate(P, p->pb, ex, L, S, bufsel, active, st);
-}
-
 // Host-mapped pass-flag arrays are recycled across plans: pinning and unpinning host memory costs more than the
 // whole solve of a small plan (one-shot gpmp2mi_batch_optimize calls create and destroy a plan each time).
 static std::mutex g_flag_mu;
@@ -331,10 +284,115 @@ static void chunk_release(void* q, int device) {
   (void)hipFree(q);
 }
 
+// live-resource counters for the lifetime tests (gpmp2mi_debug_resource_counts)
+static std::atomic<long> g_live_chunks{0}, g_live_flagbufs{0}, g_leaked_plans{0};
+
+struct gpmp2mi_plan {
+  const gpmp2mi_robot* robot = nullptr;
+  const gpmp2mi_sdf* sdf = nullptr;
+  PlanParams hp;
+  PlanBuffers pb;
+  std::vector<void*> allocs;   // arena chunks (plan_alloc)
+  std::vector<size_t> alloc_bytes;
+  char* arena_cur = nullptr;   // bump pointer into the newest chunk
+  size_t arena_left = 0;
+  int alloc_calls = 0;         // plan_alloc calls so far (GPMP2MI_FAIL_ALLOC_AT injects a failure at the k-th)
+  int device = -1;             // the device the plan was created on: its chunks / flags go back to that device's pools
+  FlagBuf flagbuf;
+  int* h_flags = nullptr;    // pinned + device-mapped [n_active_len]: per-pass active count, -1 = not yet known
+  KernelTimer timer;
+  bool wide_dense = false;   // GPMP2MI_WIDE_DENSE=1: 8..11-dof plans through the dense block solver (A/B, fallback)
+  bool generic_gn = false;   // GPMP2MI_GENERIC_GN=1: run GaussNewton through the LM/Dogleg machinery
+  int n_active_len = 0;
+  std::vector<int> h_xp_n;   // host mirror of the extra-prior counts
+  PlanExtras ex;             // extra factors carried as data (host copy of the specs + device workspace)
+  bool has_extras = false;
+  bool problem_set = false;
+  bool optimized = false;
+  // Streams that may still carry work of this plan (asynchronous copies / kernels enqueued without a closing
+  // synchronisation).  gpmp2mi_plan_destroy waits for exactly these, never for the whole device.
+  std::vector<hipStream_t> dirty_streams;
+  bool null_stream_dirty = false;
+  // A pass that did not finish within GPMP2MI_WAIT_TIMEOUT_MS: the stream may hold a hung kernel of this plan.  The
+  // plan refuses further work, and its memory is neither waited for nor recycled (a hung kernel would hang the wait,
+  // a late one would write into recycled memory): it is deliberately leaked.
+  bool poisoned = false;
+  size_t tsz() const { return (size_t)hp.B * (hp.N + 1) * hp.n; }
+  void mark_dirty(hipStream_t st) {
+    if (!st) { null_stream_dirty = true; return; }
+    if (std::find(dirty_streams.begin(), dirty_streams.end(), st) == dirty_streams.end()) dirty_streams.push_back(st);
+  }
+  void mark_clean(hipStream_t st) {
+    if (!st) { null_stream_dirty = false; return; }
+    dirty_streams.erase(std::remove(dirty_streams.begin(), dirty_streams.end(), st), dirty_streams.end());
+  }
+  // wait for whatever this plan still has in flight (a no-op after the usual optimize -> get_result sequence)
+  void drain() {
+    if (poisoned) return;
+    for (hipStream_t st : dirty_streams) (void)hipStreamSynchronize(st);
+    dirty_streams.clear();
+    if (null_stream_dirty) (void)hipStreamSynchronize(nullptr);
+    null_stream_dirty = false;
+  }
+  // Returns every arena chunk and the flag buffer (also on a create that failed half-way: the unique_ptr in
+  // gpmp2mi_plan_create runs this).  The caller has drained the plan's streams.
+  ~gpmp2mi_plan() {
+    if (poisoned) {
+      g_leaked_plans.fetch_add(1);
+      return;
+    }
+    drain();
+    for (size_t k = 0; k < allocs.size(); k++) {
+      g_live_chunks.fetch_sub(1);
+      if (alloc_bytes[k] == ARENA_CHUNK) chunk_release(allocs[k], device);
+      else (void)hipFree(allocs[k]);
+    }
+    if (flagbuf.host) {
+      g_live_flagbufs.fetch_sub(1);
+      flags_release(flagbuf);
+    }
+  }
+};
+
+static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start);
+
+// linearize `traj` into record buffer `bufsel` of every (active) trajectory: the fused obstacle / GP-prior kernel,
+// then -- only for plans that carry extra factors -- the workspace / self-collision factor kernels on the support
+// states and their accumulation into the unary records
+static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st) {
+  const PlanParams& P = p->hp;
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st));
+  if (!p->has_extras) return GPMP2MI_OK;
+  const PlanExtras& ex = p->ex;
+  const RobotDev& h = p->robot->h;
+  const int M = P.B * (P.N + 1), D = P.D, L = h.nr_links, S = h.nr_spheres;
+  if (ex.n_ws > 0) {
+    G2_TRY(launch_fk(h, p->robot->d, M, traj, ex.poses, ex.Jp, st, 2 * D));
+    for (int f = 0; f < ex.n_ws; f++)
+      G2_TRY(launch_workspace_prior(ex.ws_mode[f], ex.ws_link[f], L, D, M, ex.des + 16 * f, ex.poses, ex.Jp,
+                                    ex.ws_err + (size_t)f * M * 6, ex.ws_H + (size_t)f * M * 6 * D, st));
+  }
+  if (ex.n_sc > 0) {
+    G2_TRY(launch_sphere_centers(h, p->robot->d, M, traj, ex.cen, ex.Jc, st, 2 * D));
+    G2_TRY(launch_self_collision(ex.n_sc, S, D, M, ex.sc_data, ex.radius, ex.cen, ex.Jc, ex.sc_err, ex.sc_H, st));
+  }
+  return launch_extra_accumulate(P, p->pb, ex, L, S, bufsel, active, st);
+}
+
+// GPMP2MI_FAIL_ALLOC_AT=k (tests): the k-th plan_alloc call of every plan creation fails as if the device were out
+// of memory, so that the half-built plan's release path can be exercised
+static int fail_alloc_at() {
+  const char* e = getenv("GPMP2MI_FAIL_ALLOC_AT");
+  return e ? atoi(e) : 0;
+}
 template <class T>
 static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
   constexpr size_t ALIGN = 256, CHUNK = ARENA_CHUNK;
   const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + ALIGN - 1) / ALIGN * ALIGN;
+  if (++p->alloc_calls == fail_alloc_at()) {
+    set_error("hipMalloc: injected failure (GPMP2MI_FAIL_ALLOC_AT)");
+    return GPMP2MI_ERR_ALLOC;
+  }
   if (bytes > p->arena_left) {
     const size_t chunk = std::max(bytes, CHUNK);
     void* q = (chunk == CHUNK) ? chunk_acquire() : nullptr;
@@ -345,16 +403,28 @@ static int plan_alloc(gpmp2mi_plan* p, T** ptr, size_t count) {
         return GPMP2MI_ERR_ALLOC;
       }
     }
-    (void)hipMemset(q, 0, chunk);
+    // owned by the plan from here on: a failing memset below is released with everything else by ~gpmp2mi_plan
     p->allocs.push_back(q);
     p->alloc_bytes.push_back(chunk);
+    g_live_chunks.fetch_add(1);
     p->arena_cur = (char*)q;
     p->arena_left = chunk;
+    p->null_stream_dirty = true;   // the zero fill runs on the null stream; plan_create's closing copy waits for it
+    G2_HIP(hipMemsetAsync(q, 0, chunk, nullptr));
   }
   *ptr = (T*)p->arena_cur;
   p->arena_cur += bytes;
   p->arena_left -= bytes;
   return GPMP2MI_OK;
+}
+
+// test hook kernel (gpmp2mi_debug_stall_begin): spins on a host-mapped word, bounded by the device's real-time clock
+__global__ void k_debug_stall(const int* flag, long long max_ticks) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > max_ticks) break;
+    __builtin_amdgcn_s_sleep(64);
+  }
 }
 
 extern "C" {
@@ -923,6 +993,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_CHECK(s->total_step >= 1 && s->total_time > 0, GPMP2MI_ERR_INVALID, "bad total_step / total_time");
   G2_CHECK(s->obs_check_inter >= 0 && s->obs_check_inter <= MAXI, GPMP2MI_ERR_UNSUPPORTED, "obs_check_inter > 16");
   G2_CHECK(D <= MAXD, GPMP2MI_ERR_UNSUPPORTED, "plans are instantiated for dof <= 18");
+  // the dense path (dof > 11) exists for the reference's PR2-class models only: normal-equation export and the dense
+  // block solve are instantiated for dof 17 and 18 (plan_kernels.hip G2_EXP_CASE), so 12..16 would be created and then
+  // fail inside optimize
+  G2_CHECK(D <= 11 || D == 17 || D == 18, GPMP2MI_ERR_UNSUPPORTED,
+           "plans are instantiated for dof <= 11 and for dof 17 / 18 (SE(2) base [+ lift] + two 7-joint arms)");
   const bool wide = 2 * D > 15;  // blocks wider than one 16x16 tile: 2x2-tile cyclic reduction (dof <= 11)
   const bool dense_only = D > 11; // 12 <= dof <= 18 (PR2): dense normal equations + cyclic reduction over dense blocks
   {
@@ -942,9 +1017,10 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
       G2_CHECK(s->vel_limits[k] > 0, GPMP2MI_ERR_INVALID, "[VelocityLimitFactorVector] velocity limit <= 0");
   G2_TRY(ensure_device());
 
-  auto p = std::make_unique<gpmp2mi_plan>();
+  auto p = std::make_unique<gpmp2mi_plan>();   // ~gpmp2mi_plan returns whatever has been allocated if anything below fails
   p->robot = robot;
   p->sdf = sdf;
+  G2_HIP(hipGetDevice(&p->device));
   PlanParams& P = p->hp;
   std::memset(&P, 0, sizeof(P));
   P.B = B;
@@ -1050,6 +1126,53 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
       }
   }
 
+  // ---- extra factors as data: checked and copied to host vectors BEFORE the first allocation (an invalid
+  // description must not cost a round trip through the allocator)
+  PlanExtras& ex = p->ex;
+  std::vector<double> des, scd, radius;
+  {
+    std::memset(&ex, 0, sizeof(ex));
+    G2_CHECK(o.n_workspace >= 0 && o.n_workspace <= GPMP2MI_MAX_WORKSPACE_FACTORS, GPMP2MI_ERR_INVALID, "too many workspace factors");
+    G2_CHECK(o.n_self_collision >= 0 && o.n_self_collision <= GPMP2MI_MAX_SELF_COLLISION_PAIRS, GPMP2MI_ERR_INVALID,
+             "too many self-collision pairs");
+    const RobotDev& h = robot->h;
+    const size_t M = (size_t)B * (P.N + 1);
+    ex.n_ws = o.n_workspace;
+    ex.n_sc = o.n_self_collision;
+    des.assign(16 * std::max(ex.n_ws, 1), 0.0);
+    scd.assign(4 * std::max(ex.n_sc, 1), 0.0);
+    radius.assign(std::max(h.nr_spheres, 1), 0.0);
+    for (int f = 0; f < ex.n_ws; f++) {
+      const gpmp2mi_workspace_factor& w = o.workspace[f];
+      G2_CHECK(w.mode >= GPMP2MI_WORKSPACE_POSITION && w.mode <= GPMP2MI_WORKSPACE_POSE, GPMP2MI_ERR_INVALID, "unknown workspace factor mode");
+      G2_CHECK(w.link >= 0 && w.link < h.nr_links, GPMP2MI_ERR_INVALID, "workspace factor: link out of range");
+      G2_CHECK(w.sigma > 0, GPMP2MI_ERR_INVALID, "workspace factor: sigma must be positive");
+      G2_CHECK(w.first_state >= 0 && w.first_state <= w.last_state && w.last_state <= P.N, GPMP2MI_ERR_INVALID,
+               "workspace factor: bad state range");
+      ex.ws_mode[f] = w.mode;
+      ex.ws_link[f] = w.link;
+      ex.ws_first[f] = w.first_state;
+      ex.ws_last[f] = w.last_state;
+      ex.ws_w[f] = 1.0 / (w.sigma * w.sigma);
+      std::copy(w.des_pose, w.des_pose + 16, des.begin() + 16 * f);
+    }
+    if (ex.n_sc > 0) {
+      G2_CHECK(o.self_collision_first >= 0 && o.self_collision_first <= o.self_collision_last && o.self_collision_last <= P.N,
+               GPMP2MI_ERR_INVALID, "self collision: bad state range");
+      ex.sc_first = o.self_collision_first;
+      ex.sc_last = o.self_collision_last;
+      for (int k = 0; k < ex.n_sc; k++) {
+        const double a = o.self_collision[k][0], bb = o.self_collision[k][1], sg = o.self_collision[k][3];
+        G2_CHECK(a >= 0 && a < h.nr_spheres && bb >= 0 && bb < h.nr_spheres, GPMP2MI_ERR_INVALID, "self collision: sphere id out of range");
+        G2_CHECK(sg > 0, GPMP2MI_ERR_INVALID, "self collision: sigma must be positive");
+        for (int t = 0; t < 4; t++) scd[4 * k + t] = o.self_collision[k][t];
+        ex.sc_w[k] = 1.0 / (sg * sg);
+      }
+      for (int sidx = 0; sidx < h.nr_spheres; sidx++) radius[h.sph_orig[sidx]] = h.sph_r[sidx];
+    }
+    p->has_extras = ex.n_ws > 0 || ex.n_sc > 0;
+  }
+
   PlanBuffers& pb = p->pb;
   std::memset(&pb, 0, sizeof(pb));
   const size_t tsz = p->tsz();
@@ -1122,47 +1245,9 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     p->n_active_len = cap * mult + 3;
     P.max_pass = p->n_active_len;
   }
-  // ---- extra factors as data
   {
-    PlanExtras& ex = p->ex;
-    std::memset(&ex, 0, sizeof(ex));
-    G2_CHECK(o.n_workspace >= 0 && o.n_workspace <= GPMP2MI_MAX_WORKSPACE_FACTORS, GPMP2MI_ERR_INVALID, "too many workspace factors");
-    G2_CHECK(o.n_self_collision >= 0 && o.n_self_collision <= GPMP2MI_MAX_SELF_COLLISION_PAIRS, GPMP2MI_ERR_INVALID,
-             "too many self-collision pairs");
     const RobotDev& h = robot->h;
     const size_t M = (size_t)B * (P.N + 1);
-    ex.n_ws = o.n_workspace;
-    ex.n_sc = o.n_self_collision;
-    std::vector<double> des(16 * std::max(ex.n_ws, 1)), scd(4 * std::max(ex.n_sc, 1)), radius(std::max(h.nr_spheres, 1));
-    for (int f = 0; f < ex.n_ws; f++) {
-      const gpmp2mi_workspace_factor& w = o.workspace[f];
-      G2_CHECK(w.mode >= GPMP2MI_WORKSPACE_POSITION && w.mode <= GPMP2MI_WORKSPACE_POSE, GPMP2MI_ERR_INVALID, "unknown workspace factor mode");
-      G2_CHECK(w.link >= 0 && w.link < h.nr_links, GPMP2MI_ERR_INVALID, "workspace factor: link out of range");
-      G2_CHECK(w.sigma > 0, GPMP2MI_ERR_INVALID, "workspace factor: sigma must be positive");
-      G2_CHECK(w.first_state >= 0 && w.first_state <= w.last_state && w.last_state <= P.N, GPMP2MI_ERR_INVALID,
-               "workspace factor: bad state range");
-      ex.ws_mode[f] = w.mode;
-      ex.ws_link[f] = w.link;
-      ex.ws_first[f] = w.first_state;
-      ex.ws_last[f] = w.last_state;
-      ex.ws_w[f] = 1.0 / (w.sigma * w.sigma);
-      std::copy(w.des_pose, w.des_pose + 16, des.begin() + 16 * f);
-    }
-    if (ex.n_sc > 0) {
-      G2_CHECK(o.self_collision_first >= 0 && o.self_collision_first <= o.self_collision_last && o.self_collision_last <= P.N,
-               GPMP2MI_ERR_INVALID, "self collision: bad state range");
-      ex.sc_first = o.self_collision_first;
-      ex.sc_last = o.self_collision_last;
-      for (int k = 0; k < ex.n_sc; k++) {
-        const double a = o.self_collision[k][0], bb = o.self_collision[k][1], sg = o.self_collision[k][3];
-        G2_CHECK(a >= 0 && a < h.nr_spheres && bb >= 0 && bb < h.nr_spheres, GPMP2MI_ERR_INVALID, "self collision: sphere id out of range");
-        G2_CHECK(sg > 0, GPMP2MI_ERR_INVALID, "self collision: sigma must be positive");
-        for (int t = 0; t < 4; t++) scd[4 * k + t] = o.self_collision[k][t];
-        ex.sc_w[k] = 1.0 / (sg * sg);
-      }
-      for (int sidx = 0; sidx < h.nr_spheres; sidx++) radius[h.sph_orig[sidx]] = h.sph_r[sidx];
-    }
-    p->has_extras = ex.n_ws > 0 || ex.n_sc > 0;
     if (ex.n_ws > 0) {
       G2_TRY(plan_alloc(p.get(), &ex.des, des.size()));
       G2_HIP(hipMemcpy(ex.des, des.data(), des.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1186,34 +1271,37 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
   G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
   G2_TRY(flags_acquire(p->n_active_len, &p->flagbuf));
+  g_live_flagbufs.fetch_add(1);
   p->h_flags = p->flagbuf.host;
   pb.host_flags = p->flagbuf.dev;
   G2_TRY(plan_alloc(p.get(), &pb.done, p->n_active_len));
+  // the zero fills of the arena chunks ran on the null stream: done before the caller may use any other stream
+  G2_HIP(hipStreamSynchronize(nullptr));
+  p->null_stream_dirty = false;
   *out = p.release();
   return GPMP2MI_OK;
 }
 
-void gpmp2mi_plan_destroy(gpmp2mi_plan* p) {
-  if (!p) return;
-  (void)hipDeviceSynchronize();   // nothing of this plan is in flight any more: its chunks and flags can be reused
-  for (size_t k = 0; k < p->allocs.size(); k++) {
-    if (p->alloc_bytes[k] == ARENA_CHUNK) chunk_release(p->allocs[k], p->flagbuf.device);
-    else (void)hipFree(p->allocs[k]);
-  }
-  flags_release(p->flagbuf);
-  delete p;
-}
+// Waits only for what THIS plan still has in flight (streams it was given since their last synchronisation; nothing
+// after the usual optimize -> get_result sequence), never for the device: other host threads' plans keep running.
+// A poisoned plan (timed-out pass) is not waited for at all and its memory is not recycled.
+void gpmp2mi_plan_destroy(gpmp2mi_plan* p) { delete p; }
 
 static int plan_set_problem(gpmp2mi_plan* p, const double* sc, const double* sv, const double* ec,
                             const double* ev, const double* init, hipMemcpyKind kind, hipStream_t st) {
   G2_CHECK(p && sc && sv && ec && ev && init, GPMP2MI_ERR_INVALID, "null argument");
+  G2_CHECK(!p->poisoned, GPMP2MI_ERR_TIMEOUT, "this plan timed out earlier: destroy it and create a new one");
   const size_t bd = (size_t)p->hp.B * p->hp.D * sizeof(double);
   G2_HIP(hipMemcpyAsync(p->pb.start_conf, sc, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.start_vel, sv, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.end_conf, ec, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.end_vel, ev, bd, kind, st));
   G2_HIP(hipMemcpyAsync(p->pb.init, init, p->tsz() * sizeof(double), kind, st));
-  if (kind == hipMemcpyHostToDevice) G2_HIP(hipStreamSynchronize(st));
+  p->mark_dirty(st);
+  if (kind == hipMemcpyHostToDevice) {
+    G2_HIP(hipStreamSynchronize(st));
+    p->mark_clean(st);
+  }
   p->problem_set = true;
   p->optimized = false;
   return GPMP2MI_OK;
@@ -1274,7 +1362,7 @@ static int spin_wait_flag(const volatile int* flag, bool st_valid, hipStream_t s
       if (el > timeout_s) {
         set_error("timed out after " + std::to_string((int)(el * 1e3)) +
                   " ms waiting for a pass to finish (kernel hung?); GPMP2MI_WAIT_TIMEOUT_MS raises the limit");
-        return GPMP2MI_ERR_HIP;
+        return GPMP2MI_ERR_TIMEOUT;
       }
     }
   }
@@ -1391,15 +1479,26 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
   return GPMP2MI_OK;
 }
 static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start) {
+  G2_CHECK(!p->poisoned, GPMP2MI_ERR_TIMEOUT,
+           "this plan timed out earlier and may still have a hung kernel in its stream: destroy it and create a new one");
+  p->mark_dirty(st);
   const int rc = plan_run_impl(p, st, start);
-  // error path: the next run resets the host flags assuming the stream has drained
+  if (rc == GPMP2MI_ERR_TIMEOUT) {
+    // The stream may hold a kernel that never finishes: waiting for it here (or in gpmp2mi_plan_destroy) would hang
+    // the caller after all.  The plan is poisoned instead: no further runs, no wait and no recycling at destroy.
+    p->poisoned = true;
+    return rc;
+  }
+  // any other error: the next run resets the host flags assuming the stream has drained
   if (rc != GPMP2MI_OK) (void)hipStreamSynchronize(st);
+  p->mark_clean(st);   // plan_run_impl ends with a stream synchronisation as well
   return rc;
 }
 
 static int plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status,
                            double* trace, hipMemcpyKind kind, hipStream_t st) {
   G2_CHECK(p && p->optimized, GPMP2MI_ERR_INVALID, "plan has not been optimized");
+  G2_CHECK(!p->poisoned, GPMP2MI_ERR_TIMEOUT, "this plan timed out earlier: destroy it and create a new one");
   const int B = p->hp.B;
   if (traj) G2_HIP(hipMemcpyAsync(traj, p->pb.result, p->tsz() * sizeof(double), kind, st));
   if (iters) G2_HIP(hipMemcpyAsync(iters, p->pb.iters, B * sizeof(int), kind, st));
@@ -1407,7 +1506,11 @@ static int plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* fe
   if (status) G2_HIP(hipMemcpyAsync(status, p->pb.status, B * sizeof(int), kind, st));
   if (trace)
     G2_HIP(hipMemcpyAsync(trace, p->pb.trace, (size_t)B * (p->hp.max_iter + 1) * sizeof(double), kind, st));
-  if (kind == hipMemcpyDeviceToHost) G2_HIP(hipStreamSynchronize(st));
+  p->mark_dirty(st);
+  if (kind == hipMemcpyDeviceToHost) {
+    G2_HIP(hipStreamSynchronize(st));
+    p->mark_clean(st);
+  }
   return GPMP2MI_OK;
 }
 int gpmp2mi_plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status, double* trace) {
@@ -1617,6 +1720,51 @@ int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
 int gpmp2mi_debug_wait_flag(const int* flag, int timeout_ms, int* value) {
   G2_CHECK(flag && value && timeout_ms > 0, GPMP2MI_ERR_INVALID, "bad argument");
   return spin_wait_flag(flag, false, nullptr, timeout_ms * 1e-3, value);
+}
+
+// test hook: what the library currently holds (arena chunks / flag buffers owned by live plans, pooled ones, plans
+// leaked because they were poisoned).  Works without a GPU (all zeros then).
+int gpmp2mi_debug_resource_counts(long* live_chunks, long* pooled_chunks, long* live_flagbufs, long* pooled_flagbufs,
+                                  long* leaked_plans) {
+  std::lock_guard<std::mutex> lk(g_flag_mu);
+  if (live_chunks) *live_chunks = g_live_chunks.load();
+  if (pooled_chunks) *pooled_chunks = (long)g_chunk_pool.size();
+  if (live_flagbufs) *live_flagbufs = g_live_flagbufs.load();
+  if (pooled_flagbufs) *pooled_flagbufs = (long)g_flag_pool.size();
+  if (leaked_plans) *leaked_plans = g_leaked_plans.load();
+  return GPMP2MI_OK;
+}
+
+// test hook: a kernel that occupies `stream` until gpmp2mi_debug_stall_release (or, whatever happens, until max_ms
+// of device wall clock have passed: every wave reaches that exit), so that the pass driver's timeout path can be driven
+// on a real stream.  One thread; polls a host-mapped word.
+struct gpmp2mi_stall_token {
+  int* host = nullptr;
+  int* dev = nullptr;
+  hipStream_t st = nullptr;
+};
+int gpmp2mi_debug_stall_begin(void* stream, int max_ms, void** token) {
+  G2_CHECK(token && max_ms > 0 && max_ms <= 10000, GPMP2MI_ERR_INVALID, "bad argument");
+  G2_TRY(ensure_device());
+  auto t = std::make_unique<gpmp2mi_stall_token>();
+  G2_HIP(hipHostMalloc((void**)&t->host, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  *t->host = 0;
+  G2_HIP(hipHostGetDevicePointer((void**)&t->dev, t->host, 0));
+  t->st = (hipStream_t)stream;
+  k_debug_stall<<<dim3(1), dim3(1), 0, t->st>>>(t->dev, (long long)max_ms * 100000LL);   // s_memrealtime: 100 MHz
+  G2_HIP(hipGetLastError());
+  *token = t.release();
+  return GPMP2MI_OK;
+}
+int gpmp2mi_debug_stall_release(void* token) {
+  auto* t = static_cast<gpmp2mi_stall_token*>(token);
+  G2_CHECK(t && t->host, GPMP2MI_ERR_INVALID, "null token");
+  __atomic_store_n(t->host, 1, __ATOMIC_RELEASE);
+  const hipError_t e = hipStreamSynchronize(t->st);
+  (void)hipHostFree(t->host);
+  delete t;
+  G2_HIP(e);
+  return GPMP2MI_OK;
 }
 
 int gpmp2mi_plan_enable_timing(gpmp2mi_plan* p, int enable) {

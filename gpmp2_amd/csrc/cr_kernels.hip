@@ -18,133 +18,6 @@
 
 namespace g2 {
 
-constexpr int TILE_DBL = 256;  // doubles per tile (4 registers x 64 lanes)
-
-__device__ __forceinline__ Tile tile_load(const double* p, int lane) {
-  Tile T;
-#pragma unroll
-  for (int k = 0; k < 4; k++) T.r[k] = p[k * 64 + lane];
-  return T;
-}
-__device__ __forceinline__ void tile_store(double* p, const Tile& T, int lane) {
-#pragma unroll
-  for (int k = 0; k < 4; k++) p[k * 64 + lane] = T.r[k];
-}
-// the same for tiles whose rows >= n are structurally zero (factor and diagonal tiles of the cyclic reduction): the
-// padding rows are neither written nor read, a load leaves zeros there
-template <int n>
-__device__ __forceinline__ Tile tile_load_rows(const double* p, int lane) {
-  Tile T;
-#pragma unroll
-  for (int k = 0; k < 4; k++) T.r[k] = ((lane >> 4) + 4 * k < n) ? p[k * 64 + lane] : 0.0;
-  return T;
-}
-template <int n>
-__device__ __forceinline__ void tile_store_rows(double* p, const Tile& T, int lane) {
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if ((lane >> 4) + 4 * k < n) p[k * 64 + lane] = T.r[k];
-}
-__device__ __forceinline__ Tile tile_zero() {
-  Tile T;
-#pragma unroll
-  for (int k = 0; k < 4; k++) T.r[k] = 0.0;
-  return T;
-}
-
-// =============================================================================== CR elimination
-// Eliminate the n pivots of S = [S | b] (rhs in column RHSCOL) and apply the row operations to
-// the two coupling tiles and to V (identity on entry).  On return
-//   Cl <- R^-T Cl, Cr <- R^-T Cr (both with y = R^-T b copied into column RHSCOL), V <- R^-T.
-#ifndef G2_M_DPP
-#define G2_M_DPP 1
-#endif
-// measured on MI355X (profiles/r01_cr_variants.txt): pivot-row broadcast through ds_bpermute beats
-// the permlane-swap form (48k vs 80k cycles at the widest level); the in-row multiplier broadcast
-// is DPP row_newbcast either way.
-#ifndef G2_ROW_SWAP
-#define G2_ROW_SWAP 0
-#endif
-#ifndef G2_SUM_DPP
-#define G2_SUM_DPP 1
-#endif
-template <int n>
-__device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Tile& V, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
-  bool ok = true;
-  // pivot row j of the four tiles, broadcast to all four 16-lane rows (same column)
-  auto fetch_row = [&](auto jc, double& rS, double& rL, double& rR, double& rV) {
-    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
-#if G2_ROW_SWAP
-    rS = bcast_row<gj>(S.r[rj]);
-    rL = bcast_row<gj>(Cl.r[rj]);
-    rR = bcast_row<gj>(Cr.r[rj]);
-    rV = bcast_row<gj>(V.r[rj]);
-#else
-    const int src = gj * 16 + c;
-    rS = __shfl(S.r[rj], src, 64);
-    rL = __shfl(Cl.r[rj], src, 64);
-    rR = __shfl(Cr.r[rj], src, 64);
-    rV = __shfl(V.r[rj], src, 64);
-#endif
-  };
-  double rowS, rowL, rowR, rowV;
-  fetch_row(std::integral_constant<int, 0>{}, rowS, rowL, rowR, rowV);
-  static_for<0, n>([&](auto jc) {
-    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
-    const double piv = readlane_d(S.r[rj], gj * 16 + j);
-    ok = ok && (piv > 0.0);
-    const double inv = fast_rcp(piv);
-    auto update = [&](int k) {
-#if G2_M_DPP
-      const double m = bcast_in_row<j>(S.r[k]);
-#else
-      const double m = __shfl(S.r[k], g * 16 + j, 64);
-#endif
-      // rows at or above the pivot get a zero multiplier instead of a divergent branch; registers whose four
-      // rows are all below the pivot (4 k > j) need no test
-      const double f = (4 * k > j || g + 4 * k > j) ? m * inv : 0.0;
-      S.r[k] = fma(-f, rowS, S.r[k]);
-      Cl.r[k] = fma(-f, rowL, Cl.r[k]);
-      Cr.r[k] = fma(-f, rowR, Cr.r[k]);
-      V.r[k] = fma(-f, rowV, V.r[k]);
-    };
-    // look-ahead: the register that holds the NEXT pivot row is updated first and its broadcast is issued right
-    // away, so the cross-lane latency overlaps with the updates of the remaining registers
-    constexpr int k1 = (j + 1) >> 2;
-    double nS = 0.0, nL = 0.0, nR = 0.0, nV = 0.0;
-    if constexpr (j + 1 < n) {
-      if constexpr (4 * k1 + 3 > j) update(k1);
-      fetch_row(std::integral_constant<int, j + 1>{}, nS, nL, nR, nV);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (4 * k + 3 <= j) continue;            // rows g + 4k <= j for every g: nothing below the pivot here
-      if (j + 1 < n && k == k1) continue;      // done above
-      update(k);
-    }
-    rowS = nS; rowL = nL; rowR = nR; rowV = nV;
-  });
-  // the pivots are what is left on the diagonal (row j is final once pivot j has been applied): one gather per
-  // register instead of two selects per pivot inside the loop
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int rho = g + 4 * k;
-    const double d = __shfl(S.r[k], g * 16 + (rho & 15), 64);
-    piv_of_row[k] = (rho < n) ? d : 1.0;
-  }
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const double s = fast_rsqrt(piv_of_row[k]);
-    const double y = S.r[k] * s;
-    Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
-    Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
-    V.r[k] *= s;
-  }
-  return ok;
-}
-
 // Diagnostic build only (-DG2_STAMPS): s_memtime stamps of one workgroup's phases, written to a
 // buffer nothing else reads (cdna_hip_programming.md section 7 "In-kernel stamps").
 #ifdef G2_STAMPS
@@ -253,11 +126,9 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
       if (!lvl2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
     } else {
       // level h = 1: odd blocks only couple to their (even) neighbours
-      Tile V;
-#pragma unroll
-      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
+      Tile V;   // holds Vt = R^-1 (tiles.h: column-form elimination); read back transposed by the back-substitution
       G2_ASTAMP(3);
-      const bool ok = tile_eliminate3<n>(S, Cl, Cr, V, lane);
+      const bool ok = tile_eliminate_cv<n>(S, Cl, Cr, V, lane);
       G2_ASTAMP(4);
       double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
       tile_store_rows<n>(f, Cl, lane);
@@ -294,9 +165,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
       }
     }
     Tile V;
-#pragma unroll
-    for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
-    const bool ok = tile_eliminate3<n>(S, C2l, C2r, V, lane);
+    const bool ok = tile_eliminate_cv<n>(S, C2l, C2r, V, lane);
     double* f = pb.fac + ((size_t)b * (N + 1) + j) * 3 * TILE_DBL;
     tile_store_rows<n>(f, C2l, lane);
     tile_store_rows<n>(f + TILE_DBL, C2r, lane);
@@ -382,7 +251,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
   // updated diagonal tile back (U tasks, done by the wavefronts that have no E task).
   double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
-  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
+  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, Vt (= V^T, row-major)
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
@@ -437,9 +306,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
         continue;
       }
       Tile V;
-#pragma unroll
-      for (int k = 0; k < 4; k++) V.r[k] = (g + 4 * k == c) ? 1.0 : 0.0;
-      ok = tile_eliminate3<n>(S, Cl, Cr, V, lane) && ok;
+      ok = tile_eliminate_cv<n>(S, Cl, Cr, V, lane) && ok;
       double* f = fac + (size_t)j * 3 * TILE_DBL;
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
@@ -469,7 +336,7 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
       const double* f = fac + (size_t)block_of(h, w) * 3 * TILE_DBL;
       pWl = tile_load_rows<n>(f, lane);
       pWr = tile_load_rows<n>(f + TILE_DBL, lane);
-      pV = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
+      pV = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
     }
   };
   prefetch(hfinal);
@@ -483,7 +350,7 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
         const double* f = fac + (size_t)j * 3 * TILE_DBL;
         Wl = tile_load_rows<n>(f, lane);
         Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-        V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
+        V = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
       }
       const int jl = j - h, jr = j + h;
       const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
@@ -653,7 +520,7 @@ struct FinishGroup {
       const double* f = fac + (size_t)i * 3 * TILE_DBL;
       Wl = tile_load_rows<n>(f, lane);
       Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-      V = tile_load_rows<n>(f + 2 * TILE_DBL, lane);
+      V = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
     }
     if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(FIN_BLOCKS * q) * 16 + lane];
     if (wv == 1 && lane < 16)

@@ -183,6 +183,237 @@ __device__ __forceinline__ double tile_backsolve(const Tile& W, const Tile& V, d
   return x;
 }
 
+constexpr int TILE_DBL = 256;  // doubles per tile (4 registers x 64 lanes)
+
+__device__ __forceinline__ Tile tile_load(const double* p, int lane) {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = p[k * 64 + lane];
+  return T;
+}
+__device__ __forceinline__ void tile_store(double* p, const Tile& T, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) p[k * 64 + lane] = T.r[k];
+}
+// the same for tiles whose rows >= n are structurally zero (factor and diagonal tiles of the cyclic reduction): the
+// padding rows are neither written nor read, a load leaves zeros there
+template <int n>
+__device__ __forceinline__ Tile tile_load_rows(const double* p, int lane) {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = ((lane >> 4) + 4 * k < n) ? p[k * 64 + lane] : 0.0;
+  return T;
+}
+template <int n>
+__device__ __forceinline__ void tile_store_rows(double* p, const Tile& T, int lane) {
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if ((lane >> 4) + 4 * k < n) p[k * 64 + lane] = T.r[k];
+}
+__device__ __forceinline__ Tile tile_zero() {
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = 0.0;
+  return T;
+}
+
+// =============================================================================== CR elimination
+// Eliminate the n pivots of S = [S | b] (rhs in column RHSCOL) and apply the row operations to
+// the two coupling tiles and to V (identity on entry).  On return
+//   Cl <- R^-T Cl, Cr <- R^-T Cr (both with y = R^-T b copied into column RHSCOL), V <- R^-T.
+#ifndef G2_M_DPP
+#define G2_M_DPP 1
+#endif
+// measured on MI355X (profiles/r01_cr_variants.txt): pivot-row broadcast through ds_bpermute beats
+// the permlane-swap form (48k vs 80k cycles at the widest level); the in-row multiplier broadcast
+// is DPP row_newbcast either way.
+#ifndef G2_ROW_SWAP
+#define G2_ROW_SWAP 0
+#endif
+#ifndef G2_SUM_DPP
+#define G2_SUM_DPP 1
+#endif
+template <int n>
+__device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Tile& V, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  double piv_of_row[4] = {1.0, 1.0, 1.0, 1.0};
+  bool ok = true;
+  // pivot row j of the four tiles, broadcast to all four 16-lane rows (same column)
+  auto fetch_row = [&](auto jc, double& rS, double& rL, double& rR, double& rV) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
+#if G2_ROW_SWAP
+    rS = bcast_row<gj>(S.r[rj]);
+    rL = bcast_row<gj>(Cl.r[rj]);
+    rR = bcast_row<gj>(Cr.r[rj]);
+    rV = bcast_row<gj>(V.r[rj]);
+#else
+    const int src = gj * 16 + c;
+    rS = __shfl(S.r[rj], src, 64);
+    rL = __shfl(Cl.r[rj], src, 64);
+    rR = __shfl(Cr.r[rj], src, 64);
+    rV = __shfl(V.r[rj], src, 64);
+#endif
+  };
+  double rowS, rowL, rowR, rowV;
+  fetch_row(std::integral_constant<int, 0>{}, rowS, rowL, rowR, rowV);
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
+    const double piv = readlane_d(S.r[rj], gj * 16 + j);
+    ok = ok && (piv > 0.0);
+    const double inv = fast_rcp(piv);
+    auto update = [&](int k) {
+#if G2_M_DPP
+      const double m = bcast_in_row<j>(S.r[k]);
+#else
+      const double m = __shfl(S.r[k], g * 16 + j, 64);
+#endif
+      // rows at or above the pivot get a zero multiplier instead of a divergent branch; registers whose four
+      // rows are all below the pivot (4 k > j) need no test
+      const double f = (4 * k > j || g + 4 * k > j) ? m * inv : 0.0;
+      S.r[k] = fma(-f, rowS, S.r[k]);
+      Cl.r[k] = fma(-f, rowL, Cl.r[k]);
+      Cr.r[k] = fma(-f, rowR, Cr.r[k]);
+      V.r[k] = fma(-f, rowV, V.r[k]);
+    };
+    // look-ahead: the register that holds the NEXT pivot row is updated first and its broadcast is issued right
+    // away, so the cross-lane latency overlaps with the updates of the remaining registers
+    constexpr int k1 = (j + 1) >> 2;
+    double nS = 0.0, nL = 0.0, nR = 0.0, nV = 0.0;
+    if constexpr (j + 1 < n) {
+      if constexpr (4 * k1 + 3 > j) update(k1);
+      fetch_row(std::integral_constant<int, j + 1>{}, nS, nL, nR, nV);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (4 * k + 3 <= j) continue;            // rows g + 4k <= j for every g: nothing below the pivot here
+      if (j + 1 < n && k == k1) continue;      // done above
+      update(k);
+    }
+    rowS = nS; rowL = nL; rowR = nR; rowV = nV;
+  });
+  // the pivots are what is left on the diagonal (row j is final once pivot j has been applied): one gather per
+  // register instead of two selects per pivot inside the loop
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int rho = g + 4 * k;
+    const double d = __shfl(S.r[k], g * 16 + (rho & 15), 64);
+    piv_of_row[k] = (rho < n) ? d : 1.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double s = fast_rsqrt(piv_of_row[k]);
+    const double y = S.r[k] * s;
+    Cl.r[k] = (c == RHSCOL) ? y : Cl.r[k] * s;
+    Cr.r[k] = (c == RHSCOL) ? y : Cr.r[k] * s;
+    V.r[k] *= s;
+  }
+  return ok;
+}
+
+// =============================================================================== CR elimination, column form
+// The elimination the cyclic reduction uses since round 3 (tile_eliminate3 above stays as the measured baseline of
+// scripts/probes/elim_probe.hip and as an independent implementation for the tests).
+//
+// Row operations on [S | C_l | C_r | V] move the pivot ROW of four tiles across the four 16-lane row groups of the
+// accumulator layout (8 ds_bpermute per pivot) and update up to 16 registers per pivot.  Column operations need
+// neither: with S = L D L^T,
+//     [S ; I] L^-T = [L D ; L^-T]
+// i.e. applying to the stacked pair [S ; Vt] (Vt = I on entry) the column operations that zero row j of S right of
+// the diagonal -- column c -= column j * f_c, f_c = S'[j][c] / S'[j][j] -- leaves Vt = L^-T, and after scaling column
+// c by 1 / sqrt(pivot c), Vt = R^-1 = V^T (R the upper Cholesky factor).  Per pivot this takes
+//   * ONE cross-group broadcast (row j of S only: the multipliers f_c are per COLUMN, i.e. per lane),
+//   * column j of every register broadcast inside its 16-lane row by DPP row_newbcast FUSED into the multiply-add
+//     (v_fmac_f64_dpp: same issue cost as a plain v_fma_f64, scripts/probes/issue_cost_probe.hip),
+//   * exactly 5 such multiply-adds: S only has rows at or below the pivot's register left to update (rows above hold a
+//     zero in column j), Vt is upper triangular and only its rows at or above the pivot's register have one.
+// The factor tiles then come off the matrix cores: W = R^-T C = V C = Vt^T C = tile_atb(Vt, C), with the right-hand
+// side riding in column RHSCOL of both coupling tiles.  Vt is what goes to memory; the back-substitution, which wants
+// V in the tile layout (x = V^T t), loads it transposed (tile_load_transposed).
+// Measured (elim_probe, one wave per SIMD / 16 waves per CU): 4.0 k -> 3.3 k and 8.8 k -> 5.8 k cycles per elimination.
+template <int j, int rj, int idx>
+__device__ __forceinline__ double& elim_reg(Tile& S, Tile& Vt) {
+  // the 5 registers pivot j touches, the one holding the NEXT pivot row first: S.r[rj .. 3], then Vt.r[0 .. rj]
+  constexpr int ns = 4 - rj;
+  if constexpr (idx < ns) {
+    constexpr int first = ((j + 1) >> 2) < 4 ? ((j + 1) >> 2) : rj;   // register of row j + 1
+    constexpr int k = (idx == 0) ? first : ((rj + idx - 1 >= first) ? rj + idx : rj + idx - 1);
+    return S.r[k];
+  } else {
+    return Vt.r[idx - ns];
+  }
+}
+
+template <int n>
+__device__ __forceinline__ bool tile_eliminate_col(Tile& S, Tile& Vt, int lane) {
+  const int c = lane & 15;
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
+    const double rowS = __shfl(S.r[rj], gj * 16 + c, 64);       // S'[j][c] in every row group
+    const double piv = readlane_d(S.r[rj], gj * 16 + j);
+    const double ninv = -fast_rcp(piv);
+    const double nf = (c > j && c < n) ? rowS * ninv : 0.0;    // -f_c; columns <= j and the padding stay as they are
+    double &r0 = elim_reg<j, rj, 0>(S, Vt), &r1 = elim_reg<j, rj, 1>(S, Vt), &r2 = elim_reg<j, rj, 2>(S, Vt),
+           &r3 = elim_reg<j, rj, 3>(S, Vt), &r4 = elim_reg<j, rj, 4>(S, Vt);
+    double t0 = r0, t1 = r1, t2 = r2, t3 = r3, t4 = r4;
+    // (s_nop 1: a DPP source written by the preceding vector instruction needs two wait states; the five registers are
+    // distinct, so one pad in front of the group covers it)
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %0, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %1, %1, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %2, %2, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %3, %3, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %4, %4, %5 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+        : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4)
+        : "v"(nf), "n"(j));
+    r0 = t0; r1 = t1; r2 = t2; r3 = t3; r4 = t4;
+  });
+  // the pivots are what is left on the diagonal (column c is final once pivot c - 1 has been applied): column c needs
+  // S[c][c], held by row group c & 3 in register c >> 2
+  double pv = 1.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (4 * k >= n) continue;
+    const double dgn = __shfl(S.r[k], (c & 3) * 16 + c, 64);
+    pv = ((c >> 2) == k && c < n) ? dgn : pv;
+  }
+  const bool ok = __all(pv > 0.0);   // false for a non-positive or NaN pivot (gtsam::IndeterminantLinearSystemException)
+  const double rs = fast_rsqrt(pv);
+#pragma unroll
+  for (int k = 0; k < 4; k++) Vt.r[k] *= rs;
+  return ok;
+}
+
+// One elimination task of the cyclic reduction.  On entry S = [S | b] (right-hand side in column RHSCOL), Cl / Cr the
+// n x n couplings.  On return Cl <- W_l = R^-T C_l, Cr <- W_r = R^-T C_r, both with y = R^-T b in column RHSCOL, and
+// Vt = R^-1 (= V^T); S is destroyed.  Returns false when a pivot is not positive.
+template <int n>
+__device__ __forceinline__ bool tile_eliminate_cv(Tile& S, Tile& Cl, Tile& Cr, Tile& Vt, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    Vt.r[k] = (g + 4 * k == c && c < n) ? 1.0 : 0.0;
+    Cl.r[k] = (c == RHSCOL) ? S.r[k] : Cl.r[k];
+    Cr.r[k] = (c == RHSCOL) ? S.r[k] : Cr.r[k];
+  }
+  const bool ok = tile_eliminate_col<n>(S, Vt, lane);
+  Cl = tile_atb(Vt, Cl);
+  Cr = tile_atb(Vt, Cr);
+  return ok;
+}
+
+// V = Vt^T from the row-major Vt tile an elimination task left in memory: lane (g, c), register k <- Vt[c][g + 4 k].
+// Rows c >= n of Vt are not stored (tile_store_rows) and read as zeros; so do the rows >= n of V (columns >= n of Vt
+// are zero).  A 16-lane group reads one 32-B sector of 16 different rows per register.
+template <int n>
+__device__ __forceinline__ Tile tile_load_transposed(const double* __restrict__ p, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  Tile T;
+#pragma unroll
+  for (int k = 0; k < 4; k++) T.r[k] = (c < n && 4 * k < n) ? p[c * 16 + g + 4 * k] : 0.0;
+  return T;
+}
+
 // =============================================================================== chain solve
 // Forward elimination + back substitution of one trajectory's block-tridiagonal system.
 // `next_block(i, Dt, Wt)` fills the tiles of block i.  Writes delta [nblk][n].

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPMP2MI_LIB: another build of the same library (diagnostic / A-B builds); the default is the in-tree product library
 LIB_PATH = os.environ.get("GPMP2MI_LIB") or os.path.join(_HERE, "csrc", "libgpmp2mi.so")
 
-ERR_NAMES = {1: "invalid argument", 2: "no usable GPU", 3: "HIP error", 4: "unsupported", 5: "allocation failed"}
+ERR_NAMES = {1: "invalid argument", 2: "no usable GPU", 3: "HIP error", 4: "unsupported", 5: "allocation failed",
+             6: "timed out (plan poisoned)"}
 
 
 # per-trajectory status (include/gpmp2mi.h:51-59)

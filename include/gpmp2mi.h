@@ -44,7 +44,11 @@ enum {
   GPMP2MI_ERR_NO_DEVICE = 2,    /* no usable HIP device / kernel image */
   GPMP2MI_ERR_HIP = 3,          /* a HIP runtime call failed (see gpmp2mi_last_error) */
   GPMP2MI_ERR_UNSUPPORTED = 4,  /* combination not instantiated (dof > GPMP2MI_MAX_DOF, ...) */
-  GPMP2MI_ERR_ALLOC = 5
+  GPMP2MI_ERR_ALLOC = 5,
+  GPMP2MI_ERR_TIMEOUT = 6       /* a pass did not finish within GPMP2MI_WAIT_TIMEOUT_MS (default 5 s): the plan is
+                                   POISONED -- every later call on it returns this code, gpmp2mi_plan_destroy neither
+                                   waits for its stream nor recycles its memory (it is leaked on purpose: a hung kernel
+                                   would hang the wait, a late one would write into recycled memory) */
 };
 
 /* per-trajectory status written by the optimizers */
@@ -425,9 +429,18 @@ int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64)
 int gpmp2mi_plan_debug_scalars(gpmp2mi_plan* p, int b, double* out17);
 /* Test hook, host only (no GPU needed): the wall-clock-bounded spin the pass driver uses on its device-mapped
  * pass flags, run on a caller-owned flag: returns GPMP2MI_OK with *value = *flag once *flag >= 0, or
- * GPMP2MI_ERR_HIP (gpmp2mi_last_error set) after timeout_ms.  The driver's own limit is 5 s
+ * GPMP2MI_ERR_TIMEOUT (gpmp2mi_last_error set) after timeout_ms.  The driver's own limit is 5 s
  * (GPMP2MI_WAIT_TIMEOUT_MS overrides). */
 int gpmp2mi_debug_wait_flag(const int* flag, int timeout_ms, int* value);
+/* Test hook (works without a GPU: all zeros then): arena chunks / pass-flag buffers owned by live plans, the pooled
+ * ones, and the plans leaked because they were poisoned (GPMP2MI_ERR_TIMEOUT).  Any pointer may be NULL. */
+int gpmp2mi_debug_resource_counts(long* live_chunks, long* pooled_chunks, long* live_flagbufs, long* pooled_flagbufs,
+                                  long* leaked_plans);
+/* Test hooks: a one-thread kernel that occupies `stream` until gpmp2mi_debug_stall_release(token) -- or, whatever
+ * happens, until max_ms (<= 10000) of device wall clock have passed -- so that the pass driver's timeout path can be
+ * driven on a real stream.  release() sets the flag, waits for that stream and frees the token. */
+int gpmp2mi_debug_stall_begin(void* stream, int max_ms, void** token);
+int gpmp2mi_debug_stall_release(void* token);
 /* Diagnostic: lane semantics of the wave-level moves the solver relies on (tests/test_gpu_plan.py). */
 int gpmp2mi_debug_crosslane(const double* in64, double* out512);
 
