@@ -1497,8 +1497,9 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start) {
 
 static int plan_get_result(gpmp2mi_plan* p, double* traj, int* iters, double* ferr, int* status,
                            double* trace, hipMemcpyKind kind, hipStream_t st) {
-  G2_CHECK(p && p->optimized, GPMP2MI_ERR_INVALID, "plan has not been optimized");
+  G2_CHECK(p, GPMP2MI_ERR_INVALID, "null plan");
   G2_CHECK(!p->poisoned, GPMP2MI_ERR_TIMEOUT, "this plan timed out earlier: destroy it and create a new one");
+  G2_CHECK(p->optimized, GPMP2MI_ERR_INVALID, "plan has not been optimized");
   const int B = p->hp.B;
   if (traj) G2_HIP(hipMemcpyAsync(traj, p->pb.result, p->tsz() * sizeof(double), kind, st));
   if (iters) G2_HIP(hipMemcpyAsync(iters, p->pb.iters, B * sizeof(int), kind, st));
@@ -1743,6 +1744,20 @@ struct gpmp2mi_stall_token {
   int* dev = nullptr;
   hipStream_t st = nullptr;
 };
+// test hooks: a non-blocking HIP stream from the runtime this library is linked against (a test process must not pull
+// in a second HIP runtime just to get a stream)
+int gpmp2mi_debug_stream_create(void** stream) {
+  G2_CHECK(stream, GPMP2MI_ERR_INVALID, "null argument");
+  G2_TRY(ensure_device());
+  hipStream_t st = nullptr;
+  G2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  *stream = st;
+  return GPMP2MI_OK;
+}
+int gpmp2mi_debug_stream_destroy(void* stream) {
+  if (stream) G2_HIP(hipStreamDestroy((hipStream_t)stream));
+  return GPMP2MI_OK;
+}
 int gpmp2mi_debug_stall_begin(void* stream, int max_ms, void** token) {
   G2_CHECK(token && max_ms > 0 && max_ms <= 10000, GPMP2MI_ERR_INVALID, "bad argument");
   G2_TRY(ensure_device());

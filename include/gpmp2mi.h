@@ -440,6 +440,8 @@ int gpmp2mi_debug_resource_counts(long* live_chunks, long* pooled_chunks, long* 
  * happens, until max_ms (<= 10000) of device wall clock have passed -- so that the pass driver's timeout path can be
  * driven on a real stream.  release() sets the flag, waits for that stream and frees the token. */
 int gpmp2mi_debug_stall_begin(void* stream, int max_ms, void** token);
+int gpmp2mi_debug_stream_create(void** stream);   /* a non-blocking stream of the HIP runtime the library uses */
+int gpmp2mi_debug_stream_destroy(void* stream);
 int gpmp2mi_debug_stall_release(void* token);
 /* Diagnostic: lane semantics of the wave-level moves the solver relies on (tests/test_gpu_plan.py). */
 int gpmp2mi_debug_crosslane(const double* in64, double* out512);

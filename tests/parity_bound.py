@@ -59,8 +59,7 @@ def oracle_self_sensitivity(oracle, handles, p, ref, which=None, trials=4, seed=
 
 def check_contract(engine, oracle, p, label="", final_error_rtol=1e-9, trials=4, nthreads=None):
     """Asserts the contract for every trajectory of problem p and returns a report dict.  Trajectories above 1e-6 are
-    admitted only inside K_SELF x the oracle's own 2-ulp sensitivity; for those the final error is held to the same
-    relative bound instead of `final_error_rtol`."""
+    admitted only inside K_SELF x the oracle's own 2-ulp sensitivity."""
     res, ref, handles = solve_both(engine, oracle, p, nthreads)
     assert list(res["iters"]) == list(ref["iters"]), (label, res["iters"], ref["iters"])
     assert list(res["status"]) == list(ref["status"]), (label, res["status"], ref["status"])
@@ -73,12 +72,15 @@ def check_contract(engine, oracle, p, label="", final_error_rtol=1e-9, trials=4,
         assert np.all(d_gpu[over] <= bound), (
             f"{label}: trajectories {over.tolist()} differ from the oracle by {d_gpu[over]} but the oracle's own 2-ulp "
             f"sensitivity there is only {d_self[over]}")
-    ok = np.setdiff1d(np.arange(p.B), over)
+    # final error.  It is a deterministic function E(x) of the values a solve returns, so it is pinned in two steps:
+    # the GPU's number must be the ORACLE's E at the GPU's own trajectory to 1e-9 (this checks the error arithmetic and
+    # is free of any amplification), and the trajectories themselves are pinned above.  Where both sides returned the
+    # same trajectory to ~1e-9 the two numbers are also compared directly.
+    ro, so = handles
+    e_at_gpu = oracle.graph_error(ro, so, p.setting, *_args(p), res["traj"])
+    rel_own = np.abs(res["final_error"] / e_at_gpu - 1.0)
+    assert np.all(rel_own <= final_error_rtol), (label, rel_own.max())
     rel = np.abs(res["final_error"] / ref["final_error"] - 1.0)
-    assert np.all(rel[ok] <= final_error_rtol), (label, rel[ok].max())
-    # where the trajectory itself is only determined to d, the error (a smooth function of it) is held to the
-    # corresponding relative size
-    for b in over:
-        scale = max(np.abs(ref["traj"][b]).max(), 1.0)
-        assert rel[b] <= max(final_error_rtol, 10.0 * d_gpu[b] / scale), (label, b, rel[b], d_gpu[b])
+    same = d_gpu <= 1e-9 * np.maximum(np.abs(ref["traj"]).reshape(p.B, -1).max(axis=1), 1.0)
+    assert np.all(rel[same] <= 10.0 * final_error_rtol), (label, rel[same].max())
     return dict(d_gpu=d_gpu, d_self=d_self, over=over, rel_err=rel, res=res, ref=ref)

@@ -98,3 +98,25 @@ def test_self_collision_pairs_in_a_plan(engine, oracle):
     assert (e > 0).sum() >= 3                                  # the pairs are active on this trajectory
     _check_linearize(engine, oracle, p, traj)
     _check_solve(engine, oracle, p)
+
+
+@pytest.mark.parametrize("opt", ["GN", "LM"])
+def test_workspace_and_self_collision_factors_on_a_mobile_arm(engine, oracle, opt):
+    """the extra factors are documented for <Arm> robots (kinematics/GaussianPriorWorkspacePose.h:53-70 is templated on
+    the robot; the reference instantiates it for Arm only) but a plan accepts them for Pose2 mobile manipulators too:
+    their Jacobians then go through the Pose2 chart of the base like every other factor of the Lie path.  Pinned
+    against the oracle's factor list (parity unpinned by the reference: no fixture exists)."""
+    p = problems.mobile_arm_config5()
+    {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM}[opt]()
+    p.setting.set_obs_check_inter(2)
+    p.setting.set_max_iter(30)
+    p.setting.setOptimizationNoIncrase(True)
+    N = p.setting.total_step
+    des = np.eye(4)
+    des[:3, 3] = [0.9, 0.55, 0.0]
+    p.setting.add_workspace_prior(0, 2, des, 0.01, N // 2)             # the arm tip passes a way point half-way
+    p.setting.self_collision = np.array([[0, 9, 0.3, 0.05], [2, 8, 0.25, 0.1]])
+    p.setting.self_collision_states = (1, N - 1)
+    rng = np.random.default_rng(8)
+    _check_linearize(engine, oracle, p, p.init + 0.1 * rng.normal(size=p.init.shape))
+    _check_solve(engine, oracle, p)

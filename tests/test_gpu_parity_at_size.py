@@ -84,8 +84,11 @@ def test_config4_full_size_windows(engine, oracle):
     ref = oracle.batch_optimize(ro, so, p.setting, *args(p), p.init, nthreads=min(os.cpu_count() or 1, 64))
     assert list(res["iters"]) == [3] * 128 == list(ref["iters"])
     assert list(res["status"]) == list(ref["status"])
-    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-9)
     np.testing.assert_allclose(res["traj"], ref["traj"], atol=CONTRACT)
+    # final error: the oracle's E at the GPU's own trajectories to 1e-9; against the oracle's own run 1e-8 (three
+    # Gauss-Newton steps from a warm start turn a 1e-10 difference of the step into ~3e-9 of the error on one window)
+    np.testing.assert_allclose(res["final_error"], oracle.graph_error(ro, so, p.setting, *args(p), res["traj"]), rtol=1e-9)
+    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
     # size-independent properties: the windows start where they were told to and three iterations lower the error
     np.testing.assert_allclose(res["traj"][:, 0, :7], p.start_conf, atol=1e-3)
     np.testing.assert_allclose(res["traj"][:, -1, :7], p.end_conf, atol=1e-3)
