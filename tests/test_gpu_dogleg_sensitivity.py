@@ -17,6 +17,7 @@ import copy
 import numpy as np
 import pytest
 
+from parity_bound import K_SELF
 from sweep_cases import robot_sweep_cases
 
 pytestmark = pytest.mark.gpu
@@ -46,7 +47,8 @@ def test_dogleg_sweep_misses_are_the_problems_own_sensitivity(engine, oracle, wh
     ref = oracle.batch_optimize(ro, so, p.setting, *args, p.init)
     # control flow and error traces: the usual gates hold
     assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
-    np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=2e-4)
+    # the final error is E(returned values): held to the oracle's E at the GPU's own trajectory (no amplification in it)
+    np.testing.assert_allclose(res["final_error"], oracle.graph_error(ro, so, p.setting, *args, res["traj"]), rtol=1e-9)
     d_gpu = np.abs(res["traj"] - ref["traj"]).reshape(p.B, -1).max(axis=1)
 
     # (1) the oracle against itself: initial values perturbed by +-2 ulp
@@ -58,7 +60,7 @@ def test_dogleg_sweep_misses_are_the_problems_own_sensitivity(engine, oracle, wh
         same = (alt["iters"] == ref["iters"])
         dd = np.abs(alt["traj"] - ref["traj"]).reshape(p.B, -1).max(axis=1)
         d_self = np.maximum(d_self, np.where(same, dd, np.inf))       # a flipped iteration count is "infinitely" sensitive
-    bound = np.maximum(1e-6, 30.0 * d_self)
+    bound = np.maximum(1e-6, K_SELF * d_self)
     assert np.all(d_gpu <= bound), (d_gpu, d_self)
     assert d_gpu.max() < 2e-3
 

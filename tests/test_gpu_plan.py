@@ -504,16 +504,16 @@ def test_edge_sizes_empty_long_and_many_spheres(engine, oracle):
     import gpmp2_amd as g
     p = problems.wam_restarts(B=1, total_step=600, obs_check_inter=1, opt="GN", sdf="40", max_iter=4)
     r, s, ro, so = _handles(engine, oracle, p)
-    res = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
-    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
     # delta_t = total_time / 600 makes Q^-1 ~ 12 / delta_t^3 and the normal equations ill-conditioned: two
     # backward-stable Cholesky orders (cyclic reduction here, natural order in the oracle) then agree to
-    # ~ cond * eps only -- measured 1e-10 at N = 100, 6e-9 at N = 300, 4e-7 at N = 600
-    # (scripts/long_traj_cond.py); the control flow (iterations, status) must still be identical
-    assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"])
-    m = ~np.isnan(ref["error_trace"])
-    np.testing.assert_allclose(res["error_trace"][m], ref["error_trace"][m], rtol=1e-5)
-    np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-5)
+    # ~ cond * eps only -- measured 1e-10 at N = 100, 6e-9 at N = 300, 4e-7 at N = 600 (scripts/long_traj_cond.py).
+    # The contract stays 1e-6 (identical iterations / status); should the trajectory exceed it, the oracle's own
+    # 2-ulp sensitivity must explain it (tests/parity_bound.py).  The error of the FIRST linearization is free of any
+    # amplification and is held to 1e-9.
+    from parity_bound import check_contract
+    rep = check_contract(engine, oracle, p, label="N = 600", final_error_rtol=1e-8)
+    res, ref = rep["res"], rep["ref"]
+    np.testing.assert_allclose(res["error_trace"][:, 0], ref["error_trace"][:, 0], rtol=1e-9)
     # M = 0 evaluations are a no-op at every factor-level entry point
     z7 = np.zeros((0, 7))
     assert engine.obstacle_factor(r, s, 0.2, z7)[0].shape == (0, 16)

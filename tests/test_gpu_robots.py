@@ -5,6 +5,8 @@ sphere centres / obstacle factors / whole plans against the oracle."""
 import numpy as np
 import pytest
 
+from parity_bound import check_contract
+
 import gpmp2_amd as g
 from gpmp2_amd import problems
 from gpmp2_amd.settings import TrajOptimizerSetting
@@ -247,16 +249,13 @@ def test_wide_long_trajectories(engine, oracle, name, N):
     args = (start, z, end, z)
     r, ro = engine.robot(p.model), oracle.robot(p.model)
     s, so = engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    q = problems.Problem(name, p.model, p.sdf_origin, p.sdf_cell, p.sdf_data, p.setting, start, z, end, z.copy(), init)
     for opt in ("GN", "LM", "DOGLEG"):
         {"GN": p.setting.setGaussNewton, "LM": p.setting.setLM, "DOGLEG": p.setting.setDogleg}[opt]()
-        res = engine.batch_optimize(r, s, p.setting, *args, init)
-        ref = oracle.batch_optimize(ro, so, p.setting, *args, init)
-        assert list(res["iters"]) == list(ref["iters"]) and list(res["status"]) == list(ref["status"]), opt
-        np.testing.assert_allclose(res["final_error"], ref["final_error"], rtol=1e-8)
-        # LM: one of the N = 35 trajectories sits on a flat valley of its cost (final errors agree to 1e-9, the
-        # trajectory to 3.9e-6; the independent dense-block solver differs from the oracle by 6.8e-6 on the same
-        # trajectory and by < 1e-9 on the others -- scripts/wide_cond_probe.py), so its gate is 1e-5
-        np.testing.assert_allclose(res["traj"], ref["traj"], atol=1e-5 if opt == "LM" else 1e-6)
+        # 1e-6 for every trajectory; the one LM trajectory (N = 35) on a flat valley of its cost that round 2 gave a 1e-5
+        # gate is admitted only inside the oracle's own 2-ulp sensitivity (tests/parity_bound.py)
+        rep = check_contract(engine, oracle, q, label=f"{name} N={N} {opt}", final_error_rtol=1e-8)
+        assert rep["over"].size <= 1
 
 
 def test_wide_dense_fallback_agrees(engine, oracle, monkeypatch):
