@@ -212,49 +212,74 @@ def main():
 
     import ctypes as C
 
-    def step():
-        plan.optimize(stream=stream)
-        if world > 1:     # final gather of the results: the only collective on the path
-            eng._ck(eng.lib.gpmp2mi_plan_get_result_dev(plan.h.ptr, C.c_void_p(out_traj.data_ptr()), None, None,
-                                                        None, C.c_void_p(stream)))
-            gathered[...] = (sharding.gather_results(out_traj.cpu(), B * world).to(dev) if rehearsal
-                             else sharding.gather_results(out_traj, B * world))
+    def make_step(pl, out_t, gath, Bp):
+        """one step = the whole batch optimised; for world > 1 the final gather of the results (the only collective on the
+        path) is part of it.  HIP events around the gather give its own time."""
+        gather_events = []
+
+        def step(record=False):
+            pl.optimize(stream=stream)
+            if world > 1:
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                eng._ck(eng.lib.gpmp2mi_plan_get_result_dev(pl.h.ptr, C.c_void_p(out_t.data_ptr()), None, None,
+                                                            None, C.c_void_p(stream)))
+                gath[...] = (sharding.gather_results(out_t.cpu(), Bp * world).to(dev) if rehearsal
+                             else sharding.gather_results(out_t, Bp * world))
+                if record:
+                    e1.record()
+                    gather_events.append((e0, e1))
+        return step, gather_events
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # Per-kernel HIP events (one per kernel boundary, on the launch stream, inside the library) are recorded
-    # on every EVENT_EVERY-th step of the timed region: each event is a barrier packet between two dependent
-    # kernels (~3.4 us, 40 of them per step = 12 % of a 1 ms step when recorded on every step), so sampling keeps
-    # the instrumentation from distorting `value` while the averages still come from >= 50 launches per kernel.
-    EVENT_EVERY = 1 if os.environ.get("GPMP2MI_BENCH_EVENTS_EVERY_STEP") else 4
-    kern = {}
-    sampled = 0
-    fence()
-    t0 = time.perf_counter()
-    for it in range(args.steps):
-        timed = (it % EVENT_EVERY == 0)
-        plan.enable_timing(timed)
-        step()
-        if timed:
-            sampled += 1
-            for k, v in plan.timing().items():
-                a = kern.setdefault(k, dict(ms=0.0, launches=0))
-                a["ms"] += v["ms"]
-                a["launches"] += v["launches"]
-    fence()
-    dt = time.perf_counter() - t0
+    def timed_region(pl, step, steps, warmup, events=True):
+        """W untimed steps, then exactly K steps between two fences; returns (local wall seconds, per-kernel sums, sampled)"""
+        for _ in range(warmup):
+            step()
+        # Per-kernel HIP events (one per kernel boundary, on the launch stream, inside the library) are recorded
+        # on every EVENT_EVERY-th step of the timed region: each event is a barrier packet between two dependent
+        # kernels (~3.4 us, 40 of them per step = 12 % of a 1 ms step when recorded on every step), so sampling keeps
+        # the instrumentation from distorting `value` while the averages still come from >= 50 launches per kernel.
+        EVENT_EVERY = 1 if os.environ.get("GPMP2MI_BENCH_EVENTS_EVERY_STEP") else 4
+        kern_, sampled_ = {}, 0
+        fence()
+        t0 = time.perf_counter()
+        for it in range(steps):
+            timed = events and (it % EVENT_EVERY == 0)
+            pl.enable_timing(timed)
+            step(record=True)
+            if timed:
+                sampled_ += 1
+                for k, v in pl.timing().items():
+                    a = kern_.setdefault(k, dict(ms=0.0, launches=0))
+                    a["ms"] += v["ms"]
+                    a["launches"] += v["launches"]
+        fence()
+        return time.perf_counter() - t0, kern_, sampled_
+
+    def over_ranks(dt_local, gather_events):
+        """MAX over ranks of the wall time (the contract's clock), every rank's own time, mean gather time per step"""
+        gms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else 0.0
+        if world == 1:
+            return dt_local, [dt_local], gms
+        mine = torch.tensor([dt_local, gms], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu().numpy()
+        return float(every[:, 0].max()), [float(x) for x in every[:, 0]], float(every[:, 1].max())
+
+    step, gather_events = make_step(plan, out_traj, gathered, B)
+    dt_local, kern, sampled = timed_region(plan, step, args.steps, args.warmup)
+    dt, rank_dts, gather_ms = over_ranks(dt_local, gather_events)
     iters, status, ferr = plan.result_counts()
     passes_local = int(np.sum(iters + 1))                 # linearize+solve passes per step on this rank
     hist_local = np.bincount(status, minlength=8)[:8].astype(np.int64)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         cnt = torch.tensor([passes_local] + hist_local.tolist(), dtype=torch.int64, device=cdev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         cnt = cnt.cpu().numpy()
@@ -303,10 +328,44 @@ def main():
                                          status_counts=status_hist(vs))
             plv.close()
 
+    # BASELINE config 4 beside the headline (it is the config BASELINE.json quotes for 8 GPUs): 128 receding-horizon
+    # windows per GPU, warm-started from the solved restart-0 trajectory, 3 fixed Gauss-Newton iterations, the final
+    # gather inside the timed step; measured in the same run OUTSIDE the timed region of `value`.
+    windows = None
+    if args.workload == "restarts" and args.opt == "GN" and not args.no_variants:
+        WB = int(os.environ.get("GPMP2MI_BENCH_WINDOWS", "128"))
+        base = problems.wam_restarts(B=1, opt="GN")
+        sol = eng.batch_optimize(r, s, base.setting, base.start_conf, base.start_vel, base.end_conf, base.end_vel,
+                                 base.init)["traj"][0]
+        pw = problems.wam_windows(sol, B=WB * world)
+        wlo, whi = sharding.shard_range(WB * world, world, rank)
+        plw = eng.plan(r, s, pw.setting, WB)
+        w_in = [torch.from_numpy(np.ascontiguousarray(a[wlo:whi])).to(dev) for a in
+                (pw.start_conf, pw.start_vel, pw.end_conf, pw.end_vel, pw.init)]
+        torch.cuda.synchronize()
+        plw.set_problem_dev(*[t.data_ptr() for t in w_in], stream=stream)
+        w_out = torch.empty((WB, N + 1, 2 * D), dtype=torch.float64, device=dev)
+        w_gath = torch.empty((world * WB, N + 1, 2 * D), dtype=torch.float64, device=dev) if world > 1 else None
+        wstep, wev = make_step(plw, w_out, w_gath, WB)
+        wsteps = max(5, min(args.steps, 20))
+        wdt_local, _, _ = timed_region(plw, wstep, wsteps, 2, events=False)
+        wdt, wrank, wgather = over_ranks(wdt_local, wev)
+        wi, ws, _ = plw.result_counts()
+        windows = dict(value=WB * world * wsteps / wdt, unit="windows/sec", ms_per_step=wdt / wsteps * 1e3, steps=wsteps,
+                       config=dict(workload=("WAMReplannerExample receding horizon: 7-DOF WAM, 100 steps x 5 GP-interp, 200^3 "
+                                             f"SDF, {WB} warm-started windows per GPU, 3 fixed GN iterations"),
+                                   windows_per_gpu=WB, total_windows=WB * world, fixed_iterations=int(pw.setting.fixed_iterations)),
+                       iters=dict(min=int(wi.min()), max=int(wi.max())),
+                       rank_ms_per_step=[x / wsteps * 1e3 for x in wrank],
+                       rank_ms_spread=(max(wrank) - min(wrank)) / wsteps * 1e3,
+                       gather_ms_per_step=wgather)
+        windows_traj = (w_gath if world > 1 else torch.from_numpy(plw.result()["traj"])).cpu().numpy()
+        plw.close()
+
     dump = os.environ.get("GPMP2MI_BENCH_DUMP")     # tests: the gathered batch of the last step, for comparison
     if dump and rank == 0:                          # against a single-rank solve
         np.savez(dump, traj=(gathered if world > 1 else torch.from_numpy(plan.result()["traj"])).cpu().numpy(),
-                 iters=it_all)
+                 iters=it_all, **({"windows_traj": windows_traj} if windows else {}))
 
     if rank == 0:
         total_traj = B * world * args.steps
@@ -365,6 +424,11 @@ def main():
             out["pcie_inclusive_value"] = host_rate
         if variants:
             out["variants"] = variants
+        if windows:
+            out["windows"] = windows
+        out["rank_ms_per_step"] = [x / args.steps * 1e3 for x in rank_dts]
+        out["rank_ms_spread"] = (max(rank_dts) - min(rank_dts)) / args.steps * 1e3
+        out["gather_ms_per_step"] = gather_ms
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(os.cpu_count() or 1, 64))
             sample = args.cpu_sample or min(B, max(8, threads))

@@ -15,7 +15,7 @@ namespace g2 {
 
 // diagnostic build only: phase stamps of build_tiles for block i == 1 (slots 24.. of the trajectory's stamp row)
 #ifdef G2_STAMPS
-#define G2_BSTAMP(k) do { if (i == 1 && lane == 0 && row0 == 0 && col0 == 0) pb.stamps[(size_t)b * 64 + 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G2_BSTAMP(k) do { if (i == 1 && lane == 0 && row0 == 0 && col0 == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 24 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G2_BSTAMP(k) do {} while (0)
 #endif

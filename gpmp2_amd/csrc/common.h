@@ -16,6 +16,11 @@ constexpr int REC_G_MAX = MAXD * (MAXD + 1) / 2;
 
 // ---------------------------------------------------------------- error plumbing
 void set_error(const std::string& msg);
+// diagnostic -DG2_STAMPS builds: every kernel stamps only while the trajectory is in this iteration (its second), so the
+// 64 slots of a trajectory hold ONE pass of every kernel and differences between slots never mix passes
+#ifndef G2_STAMP_ITER
+#define G2_STAMP_ITER 1
+#endif
 #define G2_HIP(call)                                                                      \
   do {                                                                                    \
     hipError_t e_ = (call);                                                               \

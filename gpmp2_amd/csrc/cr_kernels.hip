@@ -23,14 +23,14 @@ namespace g2 {
 #ifdef G2_STAMPS
 #define G2_STAMP(k)                                                          \
   do {                                                                       \
-    if (tid == 0 && (k) < 64) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if (tid == 0 && (k) < 64 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define G2_STAMP(k) do {} while (0)
 #endif
 #ifdef G2_STAMPS
-#define G2_ASTAMP(k) do { if (i == 1 && lane == 0) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); \
-                          if (i == 2 && lane == 0) pb.stamps[(size_t)b * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G2_ASTAMP(k) do { if (i == 1 && lane == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); \
+                          if (i == 2 && lane == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G2_ASTAMP(k) do {} while (0)
 #endif

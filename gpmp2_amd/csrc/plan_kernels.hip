@@ -25,7 +25,7 @@ namespace g2 {
 
 // =============================================================================== linearize
 #ifdef G2_STAMPS
-#define G2_LSTAMP(k) do { if (chunk == 1 && threadIdx.x == 0) pb.stamps[(size_t)b * 64 + 48 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define G2_LSTAMP(k) do { if (chunk == 1 && threadIdx.x == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 48 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define G2_LSTAMP(k) do {} while (0)
 #endif
