@@ -178,6 +178,128 @@ __device__ __forceinline__ bool wtile_eliminate3(WTile& S, WTile& Cl, WTile& Cr,
   return ok;
 }
 
+// ---- column form (tiles.h "CR elimination, column form") on 2 x 2 tiles.
+// Column operations on the stacked pair [S ; Vt]: per pivot ONE row of S is moved across the row groups (two tile
+// columns: 4 ds_bpermute instead of 16), and every register that holds a row at or below the pivot (S) or at or above
+// it (Vt, upper triangular) gets one DPP-fused multiply-add per tile column right of the pivot.
+template <int jl>
+__device__ __forceinline__ void fmac_col2(double& d0, double& d1, double nf0, double nf1) {
+  // d1 += bcast_jl(d0) * nf1 ; d0 += bcast_jl(d0) * nf0   (column jl of d0 itself is not changed: nf0 is zero there)
+  asm volatile("s_nop 1\n\t"
+               "v_fmac_f64_dpp %1, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+               "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+               : "+v"(d0), "+v"(d1) : "v"(nf0), "v"(nf1), "n"(jl));
+}
+template <int jl>
+__device__ __forceinline__ void fmac_col1(double& d, double nf) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(nf), "n"(jl));
+}
+
+template <int n>
+__device__ __forceinline__ bool wtile_eliminate_col(WTile& S, WTile& Vt, int lane) {
+  const int c = lane & 15;
+  static_for<0, n>([&](auto jc) {
+    constexpr int j = decltype(jc)::value, tp = j >> 4, jl = j & 15, gj = jl & 3, rj = jl >> 2;
+    const int src = gj * 16 + c;
+    const double piv = readlane_d(S.t[tp][tp].r[rj], gj * 16 + jl);
+    const double ninv = -fast_rcp(piv);
+    // -f_c for the tile columns that hold columns right of the pivot
+    double nf[2] = {0.0, 0.0};
+#pragma unroll
+    for (int tc = tp; tc < 2; tc++) {
+      if (16 * tc >= n) continue;
+      const double rowS = __shfl(S.t[tp][tc].r[rj], src, 64);
+      const int col = 16 * tc + c;
+      nf[tc] = (col > j && col < n) ? rowS * ninv : 0.0;
+    }
+    static_for<0, 8>([&](auto qc) {
+      constexpr int tr = decltype(qc)::value >> 2, k = decltype(qc)::value & 3;
+      if constexpr (16 * tr + 4 * k < n) {
+        // S: rows at or below the pivot's register; Vt: rows at or above it
+        constexpr bool in_s = (tr > tp) || (tr == tp && k >= rj);
+        constexpr bool in_v = (tr < tp) || (tr == tp && k <= rj);
+        if constexpr (tp == 0 && n > 16) {
+          if constexpr (in_s) fmac_col2<jl>(S.t[tr][0].r[k], S.t[tr][1].r[k], nf[0], nf[1]);
+          if constexpr (in_v) fmac_col2<jl>(Vt.t[tr][0].r[k], Vt.t[tr][1].r[k], nf[0], nf[1]);
+        } else if constexpr (tp == 0) {
+          if constexpr (in_s) fmac_col1<jl>(S.t[tr][0].r[k], nf[0]);
+          if constexpr (in_v) fmac_col1<jl>(Vt.t[tr][0].r[k], nf[0]);
+        } else {   // pivot in the second tile column: only that column has entries right of it
+          if constexpr (in_s) fmac_col1<jl>(S.t[tr][1].r[k], nf[1]);
+          if constexpr (in_v) fmac_col1<jl>(Vt.t[tr][1].r[k], nf[1]);
+        }
+      }
+    });
+  });
+  // pivots = diagonal of S: column 16 tc + c needs S[col][col], held by row group c & 3, register c >> 2 of tile (tc, tc)
+  bool ok = true;
+#pragma unroll
+  for (int tc = 0; tc < 2; tc++) {
+    if (16 * tc >= n) continue;
+    double pv = 1.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (16 * tc + 4 * k >= n) continue;
+      const double dgn = __shfl(S.t[tc][tc].r[k], (c & 3) * 16 + c, 64);
+      pv = ((c >> 2) == k && 16 * tc + c < n) ? dgn : pv;
+    }
+    ok = ok && __all(pv > 0.0);
+    const double rs = fast_rsqrt(pv);
+#pragma unroll
+    for (int tr = 0; tr <= tc; tr++)     // Vt is upper triangular: tile (1, 0) stays zero
+#pragma unroll
+      for (int k = 0; k < 4; k++) Vt.t[tr][tc].r[k] *= rs;
+  }
+  return ok;
+}
+
+// One elimination task on 2 x 2 tiles; same contract as tile_eliminate_cv: Cl <- W_l, Cr <- W_r (y in column WRHS),
+// Vt = R^-1.
+template <int n>
+__device__ __forceinline__ bool wtile_eliminate_cv(WTile& S, WTile& Cl, WTile& Cr, WTile& Vt, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  Vt = wtile_zero();
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      Vt.t[ti][ti].r[k] = (g + 4 * k == c && 16 * ti + c < n) ? 1.0 : 0.0;
+      Cl.t[ti][1].r[k] = (c == 15) ? S.t[ti][1].r[k] : Cl.t[ti][1].r[k];   // right-hand side: column WRHS = 31
+      Cr.t[ti][1].r[k] = (c == 15) ? S.t[ti][1].r[k] : Cr.t[ti][1].r[k];
+    }
+  const bool ok = wtile_eliminate_col<n>(S, Vt, lane);
+  WTile Wl = wtile_zero(), Wr = wtile_zero();
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++) {
+      if (16 * ti >= n) continue;
+      Wl.t[ti][tj] = wtile_atb_ij<n>(Vt, Cl, ti, tj);
+      Wr.t[ti][tj] = wtile_atb_ij<n>(Vt, Cr, ti, tj);
+    }
+  Cl = Wl;
+  Cr = Wr;
+  return ok;
+}
+
+// V = Vt^T from the row-major Vt block in memory (see tile_load_transposed)
+template <int n>
+__device__ __forceinline__ WTile wtile_load_transposed(const double* __restrict__ p, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  WTile W;
+#pragma unroll
+  for (int tr = 0; tr < 2; tr++)
+#pragma unroll
+    for (int tc = 0; tc < 2; tc++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        // V(16 tr + g + 4 k, 16 tc + c) = Vt(16 tc + c, 16 tr + g + 4 k): tile (tc, tr) of Vt
+        const bool in = (16 * tc + c < n) && (16 * tr + 4 * k < n);
+        W.t[tr][tc].r[k] = in ? p[(2 * tc + tr) * TILE_DBL + c * 16 + g + 4 * k] : 0.0;
+      }
+  return W;
+}
+
 // x_j = V^T (y - Wl x_l - Wr x_r); xl[tc] / xr[tc] = neighbour solutions at column 16 tc + c; returns x[tc]
 template <int n>
 __device__ __forceinline__ void wcr_backsolve(const WTile& Wl, const WTile& Wr, const WTile& V, const double (&xl)[2],
@@ -325,8 +447,8 @@ __global__ __launch_bounds__(64, 2) void k_assemble_wide(const PlanParams* __res
   if (!odd) {
     wtile_store_rows<n>(pb.tiles + ((size_t)b * (N + 1) + i) * WTILE_DBL, S, lane);
   } else {
-    WTile V = wtile_identity(lane);
-    const bool ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane);
+    WTile V;   // Vt = R^-1; the back-substitution loads it transposed
+    const bool ok = wtile_eliminate_cv<n>(S, Cl, Cr, V, lane);
     double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * WTILE_DBL;
     wtile_store_rows<n>(f, Cl, lane);
     wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
@@ -437,8 +559,8 @@ __device__ __forceinline__ bool wcr_task(const PlanBuffers& pb, int b, int N, in
     wtile_store_rows<n>(tiles + (size_t)j * WTILE_DBL, S, lane);
     return true;
   }
-  WTile V = wtile_identity(lane);
-  const bool ok = wtile_eliminate3<n>(S, Cl, Cr, V, lane);
+  WTile V;
+  const bool ok = wtile_eliminate_cv<n>(S, Cl, Cr, V, lane);
   double* f = fac + (size_t)j * 3 * WTILE_DBL;
   wtile_store_rows<n>(f, Cl, lane);
   wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
@@ -506,7 +628,7 @@ __device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N
     for (int idx = w; idx < count; idx += WCR_WAVES) {
       const int j = final ? 0 : h * (2 * idx + 1);
       const double* f = fac + (size_t)j * 3 * WTILE_DBL;
-      const WTile Wl = wtile_load_rows<n>(f, lane), Wr = wtile_load_rows<n>(f + WTILE_DBL, lane), V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
+      const WTile Wl = wtile_load_rows<n>(f, lane), Wr = wtile_load_rows<n>(f + WTILE_DBL, lane), V = wtile_load_transposed<n>(f + 2 * WTILE_DBL, lane);
       const int jl = j - h, jr = j + h;
       double xl[2], xr[2], x[2];
 #pragma unroll
@@ -687,7 +809,7 @@ __global__ __launch_bounds__(512) void k_finish_trial_wide(const PlanParams* __r
   if (has_block) {
     Wl = wtile_load_rows<n>(f, lane);
     Wr = wtile_load_rows<n>(f + WTILE_DBL, lane);
-    V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
+    V = wtile_load_transposed<n>(f + 2 * WTILE_DBL, lane);
   }
   if (wv == 0 && lane < WX) xl_[0][lane] = xg[(size_t)(8 * q) * WX + lane];
   if (wv == 1 && lane < WX) xl_[8][lane] = (8 * q + 8 <= N) ? xg[(size_t)(8 * q + 8) * WX + lane] : 0.0;
