@@ -132,10 +132,26 @@ def parity_vs_oracle(ref, gpu, sample):
                 restarts_compared=int(sample))
 
 
+def head_commit():
+    """the commit this tree is at: git when .git is present, else the file scripts/evidence.sh's caller writes (the GPU
+    box gets the tree without .git)"""
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        if out.returncode == 0 and out.stdout.strip():
+            return out.stdout.strip()
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".evidence_commit")).read().strip() or None
+    except Exception:
+        return None
+
+
 def pmc_traffic():
     """HBM bytes per launch and kernel from the newest committed PMC summary under profiles/ (rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same command, gfx950
-    correction applied; see profiles/README.md).  A STORED profile, not a live measurement."""
+    correction applied; see profiles/README.md).  A STORED profile, not a live measurement: the summary records the
+    commit it was taken at, and a line produced from another commit says so (`traffic_stale`)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))   # the B = 64 GN profile of each round
     for f in reversed(files):
@@ -148,8 +164,8 @@ def pmc_traffic():
             if name.startswith("k_"):
                 out[name.split("<")[0][2:]] = v["hbm_bytes_per_launch_corrected"]
         if out:
-            return out, os.path.basename(f)
-    return None, None
+            return out, os.path.basename(f), d.get("commit")
+    return None, None, None
 
 
 def status_hist(status):
@@ -381,11 +397,24 @@ def main():
             achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
             path_gbs = ALGO_BYTES_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e9
             path_tflops = ALGO_FLOP_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e12
-            tr, tr_src = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None)
+            tr, tr_src, tr_commit = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None, None)
             traffic = sum(tr.get(k, 0.0) for k in per) if tr else None
+            here = head_commit()
+            stale = bool(tr) and (tr_commit is None or here is None or not (tr_commit.startswith(here) or here.startswith(tr_commit)))
+            if stale:
+                print(f"bench.py: the stored traffic profile {tr_src} was taken at commit {tr_commit}, this tree is at {here}: "
+                      "roofline.traffic and the per-kernel own-bytes fractions describe that commit (re-run scripts/evidence.sh)",
+                      file=sys.stderr)
+            if tr:      # every kernel judged on its OWN measured traffic: PMC bytes per launch / its mean duration / peak
+                for k, v in per.items():
+                    if k in tr and v["avg_ms"] > 0:
+                        v["own_bytes_per_launch"] = tr[k]
+                        v["own_gbs"] = tr[k] / (v["avg_ms"] * 1e-3) / 1e9
+                        v["own_frac"] = v["own_gbs"] / HBM_PEAK_GBS
             roof = dict(bound="hbm", kernel="pass: " + " + ".join(per.keys()), dominant_kernel=dom,
                         achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                         traffic=traffic, traffic_source=(tr_src + " (stored rocprofv3 PMC profile, not live)") if tr else None,
+                        traffic_commit=tr_commit if tr else None, traffic_stale=stale if tr else None,
                         algorithmic_bytes_per_launch=bytes_per_launch, avg_launch_ms=pass_ms,
                         launches_per_step=launches_per_step, units_per_launch=units_per_launch,
                         path_achieved=path_gbs, path_frac=path_gbs / HBM_PEAK_GBS,

@@ -29,6 +29,18 @@ namespace g2 {
 #define G2_STAMP(k) do {} while (0)
 #endif
 #ifdef G2_STAMPS
+// phases of ONE elimination task (wave 0 of the workgroup) at level 4 (slots 5, 6, 13, 14, 15, 29) and level 16 (slots 30, 31, 60..63)
+#define G2_TSTAMP(q)                                                                                     \
+  do {                                                                                                   \
+    if (w == 0 && lane == 0 && idx == 0 && pb.iters[b] == G2_STAMP_ITER && (h == 4 || h == 16)) {        \
+      constexpr int slot4[6] = {5, 6, 13, 14, 15, 29}, slot16[6] = {30, 31, 60, 61, 62, 63};             \
+      pb.stamps[(size_t)b * 64 + (h == 4 ? slot4[q] : slot16[q])] = __builtin_amdgcn_s_memtime();       \
+    }                                                                                                    \
+  } while (0)
+#else
+#define G2_TSTAMP(q) do {} while (0)
+#endif
+#ifdef G2_STAMPS
 #define G2_ASTAMP(k) do { if (i == 1 && lane == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 32 + (k)] = __builtin_amdgcn_s_memtime(); \
                           if (i == 2 && lane == 0 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + 40 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -281,6 +293,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       const bool em = jm >= 0, ep = jp <= N;
       const bool cm = em && elim && !final, cp = ep && elim && !final && j + h <= N;
       auto facp = [&](int blk, int which) { return fac + ((size_t)blk * 3 + which) * TILE_DBL; };
+      G2_TSTAMP(0);
       Tile S = tile_load_rows<n>(tiles + (size_t)j * TILE_DBL, lane);
       Tile T1m = tile_zero(), T1p = tile_zero(), T2m = tile_zero(), T2p = tile_zero();
       Tile Wr_m = tile_zero(), Wl_m = tile_zero(), Wl_p = tile_zero(), Wr_p = tile_zero();
@@ -293,6 +306,10 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       if (ep) Wl_p = tile_load_rows<n>(facp(jp, 0), lane);
       if (cp) Wr_p = tile_load_rows<n>(facp(jp, 1), lane);
       Tile Cl = tile_zero(), Cr = tile_zero();
+#ifdef G2_STAMPS
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+      G2_TSTAMP(1);
       if (e1m) schur_sub<n>(S, T1m, lane);
       if (e1p) schur_sub<n>(S, T1p, lane);
       if (e2m) schur_sub<n>(S, T2m, lane);
@@ -305,14 +322,24 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
         tile_store_rows<n>(tiles + (size_t)j * TILE_DBL, S, lane);
         continue;
       }
+#ifdef G2_STAMPS
+      asm volatile("" : "+v"(S.r[0]), "+v"(Cl.r[0]), "+v"(Cr.r[0]));
+#endif
+      G2_TSTAMP(2);
       Tile V;
       ok = tile_eliminate_cv<n>(S, Cl, Cr, V, lane) && ok;
+#ifdef G2_STAMPS
+      asm volatile("" : "+v"(V.r[0]), "+v"(Cl.r[0]), "+v"(Cr.r[0]));
+#endif
+      G2_TSTAMP(3);
       double* f = fac + (size_t)j * 3 * TILE_DBL;
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
       tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
+      G2_TSTAMP(4);
     }
     __syncthreads();
+    { const int idx = 0; G2_TSTAMP(5); }
     G2_STAMP(5 + __builtin_ctz(h));   // 6.. : after level h = 2, 4, ...
   }
   return ok;

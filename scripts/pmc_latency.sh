@@ -4,11 +4,12 @@ set -o pipefail
 O=gpurun_out/pmc_lat
 mkdir -p $O
 export TMPDIR=/tmp
+source scripts/lib_run.sh
 BENCH="python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-variants"
-timeout -k 10 300 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INSTS_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VMEM_RD --output-format csv -d $O/a -o a -- $BENCH > $O/a.log 2>&1; echo "a rc=$?"
-timeout -k 10 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/b -o b -- $BENCH > $O/b.log 2>&1; echo "b rc=$?"
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_LEVEL_WAVES SQ_WAVES --output-format csv -d $O/c -o c -- $BENCH > $O/c.log 2>&1; echo "c rc=$?"
-python3 scripts/pmc_sq_to_json.py $O/lat.json $O/a $O/b $O/c
+PASSES=${PASSES:-}; run a 300 rocprofv3 --pmc SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INSTS_LDS SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_VMEM_RD --output-format csv -d $O/a -o a -- $BENCH && PASSES="$PASSES $O/a"
+PASSES=${PASSES:-}; run b 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/b -o b -- $BENCH && PASSES="$PASSES $O/b"
+PASSES=${PASSES:-}; run c 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VMEM_WR SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_LEVEL_WAVES SQ_WAVES --output-format csv -d $O/c -o c -- $BENCH && PASSES="$PASSES $O/c"
+python3 scripts/pmc_sq_to_json.py $O/lat.json $PASSES
 python3 - <<'PY'
 import json
 d=json.load(open('gpurun_out/pmc_lat/lat.json'))['kernels']

@@ -2,7 +2,7 @@
 profiles/rNN_pmc_traffic.json: per kernel, mean KB per launch as reported and the gfx950-corrected HBM bytes
 (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM / rocprofv3 section).
 
-usage: python scripts/pmc_to_json.py <fetch_dir> <write_dir> <out.json>"""
+usage: python scripts/pmc_to_json.py <fetch_dir> <write_dir> <out.json> [commit]"""
 import csv
 import glob
 import json
@@ -28,6 +28,7 @@ def per_kernel(d, counter):
 
 def main():
     fdir, wdir, out = sys.argv[1:4]
+    commit = sys.argv[4] if len(sys.argv) > 4 else "unknown"
     fetch, write = per_kernel(fdir, "FETCH_SIZE"), per_kernel(wdir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) & set(write)):
@@ -40,7 +41,7 @@ def main():
             "--no-cpu-baseline), averaged per launch over all launches incl. late passes with few active trajectories. "
             "Units: KB as reported; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md 'HBM' "
             "(gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream; other widths uncalibrated).")
-    json.dump(dict(note=note, kernels=kernels), open(out, "w"), indent=1)
+    json.dump(dict(note=note, commit=commit, kernels=kernels), open(out, "w"), indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 2) for k, v in kernels.items()}))
 
 

@@ -48,6 +48,10 @@ for b in (0, 33):
     if raw[4] > raw[0] > 0:
         print("   step kernel: control", int(raw[1] - raw[0]), "forward", int(raw[2] - raw[1]), "backward", int(raw[3] - raw[2]),
               "hand-over", int(raw[4] - raw[3]), "total", int(raw[4] - raw[0]))
+    for nm, sl in (("level 4", [5, 6, 13, 14, 15, 29]), ("level 16", [30, 31, 60, 61, 62, 63])):
+        v = raw[sl]
+        if np.all(v > 0):
+            print(f"   one elimination task at {nm} (wave 0): loads / tile products / eliminate + W products / stores / wait at the barrier", d(v))
     fw = [raw[1]] + [raw[5 + k] for k in range(1, 9) if raw[5 + k] > 0]
     print("   forward levels h = 4, 8, ..:", [int(x) for x in np.diff(fw)])
     bw = [raw[2]] + [raw[16 + k] for k in range(7, -1, -1) if raw[16 + k] > 0]
