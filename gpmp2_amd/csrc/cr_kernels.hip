@@ -138,14 +138,14 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
       if (!lvl2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
     } else {
       // level h = 1: odd blocks only couple to their (even) neighbours
-      Tile V;   // holds Vt = R^-1 (tiles.h: column-form elimination); read back transposed by the back-substitution
+      Tile V;   // holds Vt = R^-1 (tiles.h: column-form elimination); stored transposed, as V
       G2_ASTAMP(3);
       const bool ok = tile_eliminate_cv<n>(S, Cl, Cr, V, lane);
       G2_ASTAMP(4);
       double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * TILE_DBL;
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
-      tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
+      tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
       if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2
         double* x = xch + (size_t)(wv >> 1) * 2 * TILE_DBL;
         tile_store(x, Cl, lane);
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
     double* f = pb.fac + ((size_t)b * (N + 1) + j) * 3 * TILE_DBL;
     tile_store_rows<n>(f, C2l, lane);
     tile_store_rows<n>(f + TILE_DBL, C2r, lane);
-    tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
+    tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
     G2_ASTAMP(7);
   }
@@ -263,7 +263,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   // of level h/2; odd multiples of h are then eliminated (E tasks), even multiples write their
   // updated diagonal tile back (U tasks, done by the wavefronts that have no E task).
   double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
-  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, Vt (= V^T, row-major)
+  double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
@@ -335,7 +335,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       double* f = fac + (size_t)j * 3 * TILE_DBL;
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
-      tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);
+      tile_store_rows<n>(f + 2 * TILE_DBL, V, lane);   // levels >= 4: Vt, loaded transposed by the back-substitution
       G2_TSTAMP(4);
     }
     __syncthreads();
@@ -343,6 +343,14 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
     G2_STAMP(5 + __builtin_ctz(h));   // 6.. : after level h = 2, 4, ...
   }
   return ok;
+}
+
+// The third factor tile of a block eliminated at level h: k_assemble (level 1, and level 2 when N >= 2) stores V, the
+// levels the step kernels run themselves store Vt (see tile_load_transposed)
+template <int n>
+__device__ __forceinline__ Tile load_v(const double* p, int h, int N, int lane) {
+  const int h0 = (N >= 2) ? 4 : 2;   // first level of cr_forward
+  return (h >= h0) ? tile_load_transposed<n>(p, lane) : tile_load_rows<n>(p, lane);
 }
 
 // Back-substitution down the same tree, levels hfinal .. hmin; leaves x of every block it reaches in
@@ -363,7 +371,7 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
       const double* f = fac + (size_t)block_of(h, w) * 3 * TILE_DBL;
       pWl = tile_load_rows<n>(f, lane);
       pWr = tile_load_rows<n>(f + TILE_DBL, lane);
-      pV = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
+      pV = load_v<n>(f + 2 * TILE_DBL, h, N, lane);
     }
   };
   prefetch(hfinal);
@@ -377,7 +385,7 @@ __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N,
         const double* f = fac + (size_t)j * 3 * TILE_DBL;
         Wl = tile_load_rows<n>(f, lane);
         Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-        V = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
+        V = load_v<n>(f + 2 * TILE_DBL, h, N, lane);
       }
       const int jl = j - h, jr = j + h;
       const double xl = (!final && jl >= 0) ? xs[jl * 16 + c] : 0.0;
@@ -547,7 +555,7 @@ struct FinishGroup {
       const double* f = fac + (size_t)i * 3 * TILE_DBL;
       Wl = tile_load_rows<n>(f, lane);
       Wr = tile_load_rows<n>(f + TILE_DBL, lane);
-      V = tile_load_transposed<n>(f + 2 * TILE_DBL, lane);
+      V = load_v<n>(f + 2 * TILE_DBL, (i & 3) ? 1 : 4, N, lane);   // blocks 8q + 4 were eliminated by the step kernel (level 4)
     }
     if (wv == 0 && lane < 16) xl_[0][lane] = xg[(size_t)(FIN_BLOCKS * q) * 16 + lane];
     if (wv == 1 && lane < 16)

@@ -327,8 +327,8 @@ __device__ __forceinline__ bool tile_eliminate3(Tile& S, Tile& Cl, Tile& Cr, Til
 //   * exactly 5 such multiply-adds: S only has rows at or below the pivot's register left to update (rows above hold a
 //     zero in column j), Vt is upper triangular and only its rows at or above the pivot's register have one.
 // The factor tiles then come off the matrix cores: W = R^-T C = V C = Vt^T C = tile_atb(Vt, C), with the right-hand
-// side riding in column RHSCOL of both coupling tiles.  Vt is what goes to memory; the back-substitution, which wants
-// V in the tile layout (x = V^T t), loads it transposed (tile_load_transposed).
+// side riding in column RHSCOL of both coupling tiles.  The back-substitution wants V in the tile layout (x = V^T t): Vt is
+// written to memory transposed (tile_store_transposed).
 // Measured (elim_probe, one wave per SIMD / 16 waves per CU): 4.0 k -> 3.3 k and 8.8 k -> 5.8 k cycles per elimination.
 template <int j, int rj, int idx>
 __device__ __forceinline__ double& elim_reg(Tile& S, Tile& Vt) {
@@ -402,9 +402,11 @@ __device__ __forceinline__ bool tile_eliminate_cv(Tile& S, Tile& Cl, Tile& Cr, T
   return ok;
 }
 
-// V = Vt^T from the row-major Vt tile an elimination task left in memory: lane (g, c), register k <- Vt[c][g + 4 k].
-// Rows c >= n of Vt are not stored (tile_store_rows) and read as zeros; so do the rows >= n of V (columns >= n of Vt
-// are zero).  A 16-lane group reads one 32-B sector of 16 different rows per register.
+// V = Vt^T from a row-major Vt tile in memory: lane (g, c), register k <- Vt[c][g + 4 k].  Rows c >= n of Vt are not
+// stored (tile_store_rows) and read as zeros; so do the rows >= n of V (columns >= n of Vt are zero).  A 16-lane group
+// reads one 32-B sector of 16 different rows per register.  Used where the WRITER is the latency-critical side (the
+// per-trajectory step kernels store Vt with plain row stores and their back-substitution levels load it this way);
+// k_assemble, whose factors the chip-wide finish kernels read, stores V itself (tile_store_transposed).
 template <int n>
 __device__ __forceinline__ Tile tile_load_transposed(const double* __restrict__ p, int lane) {
   const int c = lane & 15, g = lane >> 4;
@@ -412,6 +414,20 @@ __device__ __forceinline__ Tile tile_load_transposed(const double* __restrict__ 
 #pragma unroll
   for (int k = 0; k < 4; k++) T.r[k] = (c < n && 4 * k < n) ? p[c * 16 + g + 4 * k] : 0.0;
   return T;
+}
+
+// V = Vt^T to memory: lane (g, c), register k holds Vt[g + 4 k][c] and writes it to V[c][g + 4 k].  The four lanes that
+// share (c, k) fill one aligned 32-B sector, so every store instruction writes 16 full sectors; stores are off the
+// critical path of the elimination, while the back-substitution -- which wants V in the tile layout (x = V^T t) -- keeps
+// its plain coalesced tile loads.  (The first form of round 3 stored Vt and loaded it transposed: 16 cache lines per
+// load instruction in the latency-bound finish kernel, 6.8 -> 7.3 us.)  Rows c >= n of V and the columns >= n of its
+// rows are never written: they keep the zeros the plan's arena was created with.
+template <int n>
+__device__ __forceinline__ void tile_store_transposed(double* __restrict__ p, const Tile& Vt, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (c < n && g + 4 * k < n) p[c * 16 + g + 4 * k] = Vt.r[k];
 }
 
 // =============================================================================== chain solve

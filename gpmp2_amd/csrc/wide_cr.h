@@ -282,22 +282,19 @@ __device__ __forceinline__ bool wtile_eliminate_cv(WTile& S, WTile& Cl, WTile& C
   return ok;
 }
 
-// V = Vt^T from the row-major Vt block in memory (see tile_load_transposed)
+// V = Vt^T to memory (see tile_store_transposed): V(16 tc + c, 16 tr + g + 4 k) = Vt(16 tr + g + 4 k, 16 tc + c)
 template <int n>
-__device__ __forceinline__ WTile wtile_load_transposed(const double* __restrict__ p, int lane) {
+__device__ __forceinline__ void wtile_store_transposed(double* __restrict__ p, const WTile& Vt, int lane) {
   const int c = lane & 15, g = lane >> 4;
-  WTile W;
 #pragma unroll
   for (int tr = 0; tr < 2; tr++)
 #pragma unroll
     for (int tc = 0; tc < 2; tc++)
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        // V(16 tr + g + 4 k, 16 tc + c) = Vt(16 tc + c, 16 tr + g + 4 k): tile (tc, tr) of Vt
-        const bool in = (16 * tc + c < n) && (16 * tr + 4 * k < n);
-        W.t[tr][tc].r[k] = in ? p[(2 * tc + tr) * TILE_DBL + c * 16 + g + 4 * k] : 0.0;
+        if (16 * tr + 4 * k >= n || 16 * tc >= n) continue;
+        if (16 * tc + c < n && 16 * tr + g + 4 * k < n) p[(2 * tc + tr) * TILE_DBL + c * 16 + g + 4 * k] = Vt.t[tr][tc].r[k];
       }
-  return W;
 }
 
 // x_j = V^T (y - Wl x_l - Wr x_r); xl[tc] / xr[tc] = neighbour solutions at column 16 tc + c; returns x[tc]
@@ -447,12 +444,12 @@ __global__ __launch_bounds__(64, 2) void k_assemble_wide(const PlanParams* __res
   if (!odd) {
     wtile_store_rows<n>(pb.tiles + ((size_t)b * (N + 1) + i) * WTILE_DBL, S, lane);
   } else {
-    WTile V;   // Vt = R^-1; the back-substitution loads it transposed
+    WTile V;   // Vt = R^-1; stored transposed, as V
     const bool ok = wtile_eliminate_cv<n>(S, Cl, Cr, V, lane);
     double* f = pb.fac + ((size_t)b * (N + 1) + i) * 3 * WTILE_DBL;
     wtile_store_rows<n>(f, Cl, lane);
     wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
-    wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
+    wtile_store_transposed<n>(f + 2 * WTILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
   }
 }
@@ -564,7 +561,7 @@ __device__ __forceinline__ bool wcr_task(const PlanBuffers& pb, int b, int N, in
   double* f = fac + (size_t)j * 3 * WTILE_DBL;
   wtile_store_rows<n>(f, Cl, lane);
   wtile_store_rows<n>(f + WTILE_DBL, Cr, lane);
-  wtile_store_rows<n>(f + 2 * WTILE_DBL, V, lane);
+  wtile_store_transposed<n>(f + 2 * WTILE_DBL, V, lane);
   return ok;
 }
 
@@ -628,7 +625,7 @@ __device__ __forceinline__ void wcr_backward(const PlanBuffers& pb, int b, int N
     for (int idx = w; idx < count; idx += WCR_WAVES) {
       const int j = final ? 0 : h * (2 * idx + 1);
       const double* f = fac + (size_t)j * 3 * WTILE_DBL;
-      const WTile Wl = wtile_load_rows<n>(f, lane), Wr = wtile_load_rows<n>(f + WTILE_DBL, lane), V = wtile_load_transposed<n>(f + 2 * WTILE_DBL, lane);
+      const WTile Wl = wtile_load_rows<n>(f, lane), Wr = wtile_load_rows<n>(f + WTILE_DBL, lane), V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
       const int jl = j - h, jr = j + h;
       double xl[2], xr[2], x[2];
 #pragma unroll
@@ -809,7 +806,7 @@ __global__ __launch_bounds__(512) void k_finish_trial_wide(const PlanParams* __r
   if (has_block) {
     Wl = wtile_load_rows<n>(f, lane);
     Wr = wtile_load_rows<n>(f + WTILE_DBL, lane);
-    V = wtile_load_transposed<n>(f + 2 * WTILE_DBL, lane);
+    V = wtile_load_rows<n>(f + 2 * WTILE_DBL, lane);
   }
   if (wv == 0 && lane < WX) xl_[0][lane] = xg[(size_t)(8 * q) * WX + lane];
   if (wv == 1 && lane < WX) xl_[8][lane] = (8 * q + 8 <= N) ? xg[(size_t)(8 * q + 8) * WX + lane] : 0.0;
