@@ -1223,6 +1223,8 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.gpu2, (size_t)B * P.GPS * P.Npad));
   G2_TRY(plan_alloc(p.get(), &pb.tiles, (size_t)B * (P.N + 1) * 256 * tq));
   G2_TRY(plan_alloc(p.get(), &pb.fac, (size_t)B * (P.N + 1) * 768 * tq));
+  G2_TRY(plan_alloc(p.get(), &pb.pend, (size_t)B * ((P.N + 4) / 4) * 256));
+  G2_TRY(plan_alloc(p.get(), &pb.coup, (size_t)B * ((P.N + 4) / 4) * 256));
   G2_TRY(plan_alloc(p.get(), &pb.cur_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.prev_err, B));
   G2_TRY(plan_alloc(p.get(), &pb.last_err, B));
@@ -1721,6 +1723,15 @@ int gpmp2mi_debug_crosslane(const double* in64, double* out512) {
 int gpmp2mi_debug_wait_flag(const int* flag, int timeout_ms, int* value) {
   G2_CHECK(flag && value && timeout_ms > 0, GPMP2MI_ERR_INVALID, "bad argument");
   return spin_wait_flag(flag, false, nullptr, timeout_ms * 1e-3, value);
+}
+
+// diagnostic: raw copy of one of the solver's hand-over buffers (0 tiles, 1 fac, 2 pend, 3 coup) to the host
+int gpmp2mi_plan_debug_read(gpmp2mi_plan* p, int which, double* out, long count) {
+  G2_CHECK(p && out && count >= 0, GPMP2MI_ERR_INVALID, "bad argument");
+  const double* src = which == 0 ? p->pb.tiles : which == 1 ? p->pb.fac : which == 2 ? p->pb.pend : which == 3 ? p->pb.coup : nullptr;
+  G2_CHECK(src, GPMP2MI_ERR_INVALID, "unknown buffer");
+  G2_HIP(hipMemcpy(out, src, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+  return GPMP2MI_OK;
 }
 
 // test hook: what the library currently holds (arena chunks / flag buffers owned by live plans, pooled ones, plans

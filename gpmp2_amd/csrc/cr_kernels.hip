@@ -56,6 +56,35 @@ __device__ __forceinline__ void schur_sub(Tile& S, const Tile& A, int lane) {
   for (int k = 0; k < 4; k++)
     if ((g + 4 * k) < n && (c < n || c == RHSCOL)) S.r[k] -= T.r[k];
 }
+// A^T A restricted like schur_sub (real rows, matrix + rhs columns), as a tile of its own.
+// The restriction is a v_cndmask on a LITERAL lane mask (inline asm): written in C++ as
+// `rows && (c < n || c == RHSCOL) ? t : 0.0` -- also with non-short-circuit operators -- hipcc 7.2 lowered the select for
+// n = 4, 6, 8 (registers whose row test is compile-time true) to exec-masked control flow that zeroed EVERY column below
+// RHSCOL, i.e. the whole matrix part (s_and_saveexec on c < 15, the zero move, and only then the c < 8 test); found
+// through the planar-arm cases of tests/test_gpu_plan.py, scripts/probes/fold_debug2.py shows the tile.
+constexpr unsigned long long schur_mask(int n, int k) {
+  unsigned long long m = 0;
+  for (int g = 0; g < 4; g++)
+    for (int c = 0; c < 16; c++)
+      if (g + 4 * k < n && (c < n || c == RHSCOL)) m |= 1ull << (16 * g + c);
+  return m;
+}
+template <unsigned long long M>
+__device__ __forceinline__ double keep_lanes(double x) {   // x in the lanes whose bit is set in M, 0.0 elsewhere
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  const unsigned long long m = M;
+  asm("v_cndmask_b32_e64 %0, 0, %0, %2\n\tv_cndmask_b32_e64 %1, 0, %1, %2" : "+v"(lo), "+v"(hi) : "s"(m));
+  return __hiloint2double(hi, lo);
+}
+template <int n>
+__device__ __forceinline__ Tile schur_prod(const Tile& A, int lane) {
+  Tile T = tile_atb(A, A);
+  T.r[0] = keep_lanes<schur_mask(n, 0)>(T.r[0]);
+  T.r[1] = keep_lanes<schur_mask(n, 1)>(T.r[1]);
+  T.r[2] = keep_lanes<schur_mask(n, 2)>(T.r[2]);
+  T.r[3] = keep_lanes<schur_mask(n, 3)>(T.r[3]);
+  return T;
+}
 // -(A^T B) restricted to the n x n matrix part
 template <int n>
 __device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane) {
@@ -72,6 +101,15 @@ __device__ __forceinline__ Tile coupling(const Tile& A, const Tile& B, int lane)
 // chip: odd blocks (r = 1, 3) are eliminated as soon as they are formed; block 4q + 2 then absorbs
 // their Schur complements (handed over through LDS), gets its fill-in couplings to 4q and 4q + 4 and is
 // eliminated too.  The per-trajectory solve kernels start at level 4 (cr_forward).
+//
+// Round 3: everything the eliminated blocks of the group owe to the surviving multiples of 4 is FOLDED here as well,
+// on matrix cores that this (vector-issue bound) kernel leaves idle, instead of in the per-trajectory step kernel whose
+// first two levels were bound by exactly these products (416 + 408 v_mfma_f64 per trajectory on ONE compute unit):
+//   * S(4q)   -= W_l(4q+1)^T W_l(4q+1) + W_l(4q+2)^T W_l(4q+2)              written back as the block's diagonal tile
+//   * pend[q]  = W_r(4q+3)^T W_r(4q+3) + W_r(4q+2)^T W_r(4q+2)              what block 4q + 4 (next group) still owes
+//   * coup[q]  = the fill-in coupling between 4q and 4q + 4 through 4q + 2, in the orientation of whichever of the
+//                two is eliminated at level 4 (the odd multiple of 4): rows 4q, cols 4q+4 for odd q, the transpose else
+// so that a level-4 task is: S - pend, two ready-made couplings, eliminate -- no tile product in front of it.
 constexpr int ASM_WAVES = 4;
 // register budget of k_assemble: wavefronts per SIMD the kernel must leave room for (5 -> <= 96 VGPRs)
 #ifndef G2_ASM_MINW
@@ -99,7 +137,9 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
   // the 4 blocks of the group need the 5 intervals 4q .. 4q+4; every interval is staged once, into a slot all
   // wavefronts can read: wavefront wv stages interval 4q + wv (the last one also 4q + 4) and then uses slots
   // wv (interval i) and wv + 1 (interval i + 1)
-  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.RECS, P.GPS);   // [2 odd blocks][Wl, Wr]
+  // hand-over tiles: [0] W_l, [1] W_r of block 4q+1; [2] W_l, [3] W_r of block 4q+3; [4] S of block 4q;
+  // [5] W_l(4q+1)^T W_l(4q+1); [6] W_r(4q+3)^T W_r(4q+3)
+  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.RECS, P.GPS);
   const double* rec = rec_of(pb, pb.which[b], bufsel);
   const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
@@ -135,7 +175,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
         if (g + 4 * k == c && c < n) S.r[k] += lam;
     }
     if (!odd) {
-      if (!lvl2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
+      if (!fuse2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
+      else if (wv == 0) tile_store(xch + 4 * TILE_DBL, S, lane);   // folded and written back by wavefront 2
     } else {
       // level h = 1: odd blocks only couple to their (even) neighbours
       Tile V;   // holds Vt = R^-1 (tiles.h: column-form elimination); stored transposed, as V
@@ -146,10 +187,12 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
       tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
-      if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2
+      if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2, and what the multiple of 4 next to this block owes
         double* x = xch + (size_t)(wv >> 1) * 2 * TILE_DBL;
         tile_store(x, Cl, lane);
         tile_store(x + TILE_DBL, Cr, lane);
+        if (wv == 1) tile_store(xch + 5 * TILE_DBL, schur_prod<n>(Cl, lane), lane);
+        else if (ASM_WAVES * q + 4 <= N) tile_store(xch + 6 * TILE_DBL, schur_prod<n>(Cr, lane), lane);
       }
       if (!ok && lane == 0) pb.notspd[b] = 1;
       G2_ASTAMP(5);
@@ -158,10 +201,20 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
   if (!fuse2) return;
   __syncthreads();
   G2_ASTAMP(6);
-  if (!lvl2) return;
-  // level h = 2, block j = 4q + 2 (an odd multiple of 2): the E task of cr_forward with the
-  // neighbours' factor tiles taken from LDS
-  {
+  if (wv != 2) return;
+  // wavefront 2: level h = 2 for block j = 4q + 2 (an odd multiple of 2; the E task of cr_forward with the neighbours'
+  // factor tiles taken from LDS) when that block exists, and the folding for block 4q / the next group either way
+  const int j0 = ASM_WAVES * q;
+  const bool next = j0 + 4 <= N;
+  Tile Sp = tile_load(xch + 4 * TILE_DBL, lane);              // S of block 4q
+  if (j0 + 1 <= N) {
+    const Tile A1 = tile_load(xch + 5 * TILE_DBL, lane);
+#pragma unroll
+    for (int k = 0; k < 4; k++) Sp.r[k] -= A1.r[k];
+  }
+  Tile R = tile_zero();
+  if (next && j0 + 3 <= N) R = tile_load(xch + 6 * TILE_DBL, lane);
+  if (live) {
     const int j = i;
     const Tile Wr_m = tile_load(xch + TILE_DBL, lane);       // block j - 1: W_r
     schur_sub<n>(S, Wr_m, lane);
@@ -183,14 +236,27 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
     tile_store_rows<n>(f + TILE_DBL, C2r, lane);
     tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
+    const Tile A2 = schur_prod<n>(C2l, lane);                // W_l(j)^T W_l(j): owed by block 4q
+#pragma unroll
+    for (int k = 0; k < 4; k++) Sp.r[k] -= A2.r[k];
+    if (next) {
+      const Tile B2 = schur_prod<n>(C2r, lane);              // W_r(j)^T W_r(j): owed by block 4q + 4
+#pragma unroll
+      for (int k = 0; k < 4; k++) R.r[k] += B2.r[k];
+      // fill-in between 4q and 4q + 4: rows of the one that level 4 eliminates
+      const Tile K = (q & 1) ? coupling<n>(C2l, C2r, lane) : coupling<n>(C2r, C2l, lane);
+      tile_store_rows<n>(pb.coup + ((size_t)b * groups + q) * TILE_DBL, K, lane);
+    }
     G2_ASTAMP(7);
   }
+  tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + j0) * TILE_DBL, Sp, lane);
+  if (next) tile_store_rows<n>(pb.pend + ((size_t)b * groups + q) * TILE_DBL, R, lane);
 }
 
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st) {
   const dim3 grid(hp.B * ((hp.N + ASM_WAVES) / ASM_WAVES)), block(64 * ASM_WAVES);
-  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) + 4 * TILE_DBL) * sizeof(double);
+  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) + 7 * TILE_DBL) * sizeof(double);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
   case DD:                                                                                              \
@@ -267,9 +333,8 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   bool ok = true;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
-  // levels 1 and 2 were done by k_assemble (level 2 only when it is not the final one, N >= 2); the
-  // level-2 updates of the surviving blocks (multiples of 4) were NOT applied there, so they are
-  // absorbed together with the level-4 ones
+  // levels 1 and 2 were done by k_assemble (level 2 only when it is not the final one, N >= 2), including
+  // their Schur complements on the surviving blocks (multiples of 4) and the level-4 couplings
   const int h0 = (N >= 2) ? 4 : 2;
   // Level 4 would be 13 E + 13 U tasks on 16 wavefronts (two rounds) for N = 100: its U tasks (the blocks that
   // are multiples of 8) are deferred -- at level 8 every task absorbs the Schur complements of its level-1,
@@ -286,38 +351,46 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
       // every tile this task needs is requested before the first product: the level-1 / level-2 factors come from
       // the previous kernel (other XCDs' L2 -> Infinity Cache / HBM latency), and one latency is paid instead of
       // one per neighbour
-      const bool p1 = h0 == 4 && (h == 4 || (defer4 && h == 8));   // pending level-1 Schur complements
-      const bool p2 = defer4 && h == 8;                             // ... and the level-2 ones deferred from level 4
-      const int jm = j - hh, jp = j + hh;
-      const bool e1m = p1 && j - 1 >= 0, e1p = p1 && j + 1 <= N, e2m = p2 && j - 2 >= 0, e2p = p2 && j + 2 <= N;
+      // k_assemble has folded everything the level-1 / level-2 blocks owe to the multiples of 4 (its header comment):
+      // the first task that touches such a block here -- level 4 for the odd multiples of 4, level 8 for the multiples
+      // of 8 -- only subtracts what the previous group left pending for it, and a level-4 task takes its two couplings
+      // ready-made.  Every tile is requested before the first product (one latency per task, not one per neighbour).
+      const bool first = h0 == 4 && (h == 4 || (defer4 && h == 8));
+      const bool ready = h0 == 4 && h == 4;          // level-2 neighbours already absorbed, couplings precomputed
+      const int jm = j - hh, jp = j + hh, qj = j >> 2;
       const bool em = jm >= 0, ep = jp <= N;
       const bool cm = em && elim && !final, cp = ep && elim && !final && j + h <= N;
       auto facp = [&](int blk, int which) { return fac + ((size_t)blk * 3 + which) * TILE_DBL; };
+      const int groups = (N + 4) / 4;
+      const double* pend = pb.pend + (size_t)b * groups * TILE_DBL;
+      const double* coup = pb.coup + (size_t)b * groups * TILE_DBL;
       G2_TSTAMP(0);
       Tile S = tile_load_rows<n>(tiles + (size_t)j * TILE_DBL, lane);
-      Tile T1m = tile_zero(), T1p = tile_zero(), T2m = tile_zero(), T2p = tile_zero();
+      Tile Pd = tile_zero();
       Tile Wr_m = tile_zero(), Wl_m = tile_zero(), Wl_p = tile_zero(), Wr_p = tile_zero();
-      if (e1m) T1m = tile_load_rows<n>(facp(j - 1, 1), lane);
-      if (e1p) T1p = tile_load_rows<n>(facp(j + 1, 0), lane);
-      if (e2m) T2m = tile_load_rows<n>(facp(j - 2, 1), lane);
-      if (e2p) T2p = tile_load_rows<n>(facp(j + 2, 0), lane);
-      if (em) Wr_m = tile_load_rows<n>(facp(jm, 1), lane);
-      if (cm) Wl_m = tile_load_rows<n>(facp(jm, 0), lane);
-      if (ep) Wl_p = tile_load_rows<n>(facp(jp, 0), lane);
-      if (cp) Wr_p = tile_load_rows<n>(facp(jp, 1), lane);
       Tile Cl = tile_zero(), Cr = tile_zero();
+      if (first && qj >= 1) Pd = tile_load_rows<n>(pend + (size_t)(qj - 1) * TILE_DBL, lane);
+      if (ready) {
+        if (cm) Cl = tile_load_rows<n>(coup + (size_t)(qj - 1) * TILE_DBL, lane);
+        if (cp) Cr = tile_load_rows<n>(coup + (size_t)qj * TILE_DBL, lane);
+      } else {
+        if (em) Wr_m = tile_load_rows<n>(facp(jm, 1), lane);
+        if (cm) Wl_m = tile_load_rows<n>(facp(jm, 0), lane);
+        if (ep) Wl_p = tile_load_rows<n>(facp(jp, 0), lane);
+        if (cp) Wr_p = tile_load_rows<n>(facp(jp, 1), lane);
+      }
 #ifdef G2_STAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       G2_TSTAMP(1);
-      if (e1m) schur_sub<n>(S, T1m, lane);
-      if (e1p) schur_sub<n>(S, T1p, lane);
-      if (e2m) schur_sub<n>(S, T2m, lane);
-      if (e2p) schur_sub<n>(S, T2p, lane);
-      if (em) schur_sub<n>(S, Wr_m, lane);
-      if (cm) Cl = coupling<n>(Wr_m, Wl_m, lane);  // rows j, cols j - h
-      if (ep) schur_sub<n>(S, Wl_p, lane);
-      if (cp) Cr = coupling<n>(Wl_p, Wr_p, lane);  // rows j, cols j + h
+#pragma unroll
+      for (int k = 0; k < 4; k++) S.r[k] -= Pd.r[k];
+      if (!ready) {
+        if (em) schur_sub<n>(S, Wr_m, lane);
+        if (cm) Cl = coupling<n>(Wr_m, Wl_m, lane);  // rows j, cols j - h
+        if (ep) schur_sub<n>(S, Wl_p, lane);
+        if (cp) Cr = coupling<n>(Wl_p, Wr_p, lane);  // rows j, cols j + h
+      }
       if (!elim) {
         tile_store_rows<n>(tiles + (size_t)j * TILE_DBL, S, lane);
         continue;

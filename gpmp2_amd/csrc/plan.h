@@ -83,6 +83,8 @@ struct PlanBuffers {
   double* gpu2;
   double* tiles;           // [B][N+1][256] diagonal tile S_i = [D_i | -g_i] of every even block (updated in place)
   double* fac;             // [B][N+1][3][256] factor tiles Wl, Wr (both carry y), V = R^-T
+  double* pend;            // [B][ceil((N+1)/4)][256] what block 4q+4 still owes to blocks 4q+2, 4q+3 (k_assemble -> cr_forward)
+  double* coup;            // [B][ceil((N+1)/4)][256] level-4 coupling between blocks 4q and 4q+4 (k_assemble -> cr_forward)
   double* delta;           // [B][N+1][2D]
   double* gvec;            // [B][N+1][16] gradient g_i = J^T Sigma^-1 r of the current linearization
   double* htiles;          // [B][N+1][2][256] un-eliminated D_i and H_{i,i+1} (Dogleg: g^T H g)

@@ -445,6 +445,9 @@ int gpmp2mi_debug_stream_destroy(void* stream);
 int gpmp2mi_debug_stall_release(void* token);
 /* Diagnostic: lane semantics of the wave-level moves the solver relies on (tests/test_gpu_plan.py). */
 int gpmp2mi_debug_crosslane(const double* in64, double* out512);
+/* Diagnostic: raw device-to-host copy of a solver hand-over buffer of the plan (0: diagonal tiles [B][N+1][256],
+ * 1: factor tiles [B][N+1][3][256], 2: pending Schur tiles [B][groups][256], 3: level-4 couplings [B][groups][256]). */
+int gpmp2mi_plan_debug_read(gpmp2mi_plan* p, int which, double* out, long count);
 
 #ifdef __cplusplus
 }
