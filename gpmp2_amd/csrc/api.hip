@@ -1270,7 +1270,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     }
   }
   G2_TRY(plan_alloc(p.get(), &pb.n_active, p->n_active_len));
-  G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 64));
+  G2_TRY(plan_alloc(p.get(), &pb.stamps, (size_t)B * 128));   // rows 0..B-1: kernel phases, rows B..2B-1: one CR task per level
   G2_HIP(hipMemcpy(pb.params, &P, sizeof(P), hipMemcpyHostToDevice));
   G2_TRY(flags_acquire(p->n_active_len, &p->flagbuf));
   g_live_flagbufs.fetch_add(1);
@@ -1692,7 +1692,8 @@ int gpmp2mi_collision_cost(const gpmp2mi_robot* r, const gpmp2mi_sdf* s, int tot
 
 // diagnostic: raw s_memtime stamps of the last step kernel (all zero unless built with -DG2_STAMPS)
 int gpmp2mi_plan_debug_stamps(gpmp2mi_plan* p, int b, unsigned long long* out64) {
-  G2_CHECK(p && out64 && b >= 0 && b < p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
+  // rows B .. 2B - 1 hold the per-task stamps of the cyclic reduction (G2_TSTAMP) of trajectory b - B
+  G2_CHECK(p && out64 && b >= 0 && b < 2 * p->hp.B, GPMP2MI_ERR_INVALID, "bad argument");
   G2_HIP(hipMemcpy(out64, p->pb.stamps + (size_t)b * 64, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return GPMP2MI_OK;
 }

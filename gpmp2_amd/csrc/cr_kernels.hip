@@ -29,13 +29,12 @@ namespace g2 {
 #define G2_STAMP(k) do {} while (0)
 #endif
 #ifdef G2_STAMPS
-// phases of ONE elimination task (wave 0 of the workgroup) at level 4 (slots 5, 6, 13, 14, 15, 29) and level 16 (slots 30, 31, 60..63)
+// phases of ONE elimination task (wave 0 of the workgroup) at levels 4, 8 and 16: second stamp region of the plan (row
+// B + b), slots 0..5 / 8..13 / 16..21
 #define G2_TSTAMP(q)                                                                                     \
   do {                                                                                                   \
-    if (w == 0 && lane == 0 && idx == 0 && pb.iters[b] == G2_STAMP_ITER && (h == 4 || h == 16)) {        \
-      constexpr int slot4[6] = {5, 6, 13, 14, 15, 29}, slot16[6] = {30, 31, 60, 61, 62, 63};             \
-      pb.stamps[(size_t)b * 64 + (h == 4 ? slot4[q] : slot16[q])] = __builtin_amdgcn_s_memtime();       \
-    }                                                                                                    \
+    if (w == 0 && lane == 0 && idx == 0 && pb.iters[b] == G2_STAMP_ITER && (h == 4 || h == 8 || h == 16)) \
+      pb.stamps[((size_t)gridDim.x + b) * 64 + (h == 4 ? 0 : h == 8 ? 8 : 16) + (q)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define G2_TSTAMP(q) do {} while (0)
@@ -77,12 +76,16 @@ __device__ __forceinline__ double keep_lanes(double x) {   // x in the lanes who
   return __hiloint2double(hi, lo);
 }
 template <int n>
-__device__ __forceinline__ Tile schur_prod(const Tile& A, int lane) {
-  Tile T = tile_atb(A, A);
+__device__ __forceinline__ void schur_keep(Tile& T) {
   T.r[0] = keep_lanes<schur_mask(n, 0)>(T.r[0]);
   T.r[1] = keep_lanes<schur_mask(n, 1)>(T.r[1]);
   T.r[2] = keep_lanes<schur_mask(n, 2)>(T.r[2]);
   T.r[3] = keep_lanes<schur_mask(n, 3)>(T.r[3]);
+}
+template <int n>
+__device__ __forceinline__ Tile schur_prod(const Tile& A, int lane) {
+  Tile T = tile_atb(A, A);
+  schur_keep<n>(T);
   return T;
 }
 // -(A^T B) restricted to the n x n matrix part
@@ -137,9 +140,11 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
   // the 4 blocks of the group need the 5 intervals 4q .. 4q+4; every interval is staged once, into a slot all
   // wavefronts can read: wavefront wv stages interval 4q + wv (the last one also 4q + 4) and then uses slots
   // wv (interval i) and wv + 1 (interval i + 1)
-  // hand-over tiles: [0] W_l, [1] W_r of block 4q+1; [2] W_l, [3] W_r of block 4q+3; [4] S of block 4q;
-  // [5] W_l(4q+1)^T W_l(4q+1); [6] W_r(4q+3)^T W_r(4q+3)
-  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * Asm::slot_doubles(P.I, P.RECS, P.GPS);
+  // hand-over tiles: [0] W_l, [1] W_r of block 4q+1; [2] W_l, [3] W_r of block 4q+3; S of block 4q goes where only its
+  // own wavefront has read -- record slot 0 -- when a slot holds a tile, otherwise into a fifth tile
+  const int slotd = Asm::slot_doubles(P.I, P.RECS, P.GPS);
+  double* xch = asm_smem + (size_t)(ASM_WAVES + 1) * slotd;
+  double* xs0 = (slotd >= TILE_DBL) ? asm_smem : xch + 4 * TILE_DBL;
   const double* rec = rec_of(pb, pb.which[b], bufsel);
   const double* gpu = gpu_of(pb, pb.which[b], bufsel);
   Asm as(P, pb, rec, gpu, b, lane);
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
     }
     if (!odd) {
       if (!fuse2) tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + i) * TILE_DBL, S, lane);
-      else if (wv == 0) tile_store(xch + 4 * TILE_DBL, S, lane);   // folded and written back by wavefront 2
+      else if (wv == 0) tile_store(xs0, S, lane);   // folded and written back by wavefront 2
     } else {
       // level h = 1: odd blocks only couple to their (even) neighbours
       Tile V;   // holds Vt = R^-1 (tiles.h: column-form elimination); stored transposed, as V
@@ -187,12 +192,10 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
       tile_store_rows<n>(f, Cl, lane);
       tile_store_rows<n>(f + TILE_DBL, Cr, lane);
       tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
-      if (fuse2) {  // hand W_l, W_r to the wavefront of block 4q + 2, and what the multiple of 4 next to this block owes
+      if (fuse2) {  // hand W_l, W_r to wavefront 2
         double* x = xch + (size_t)(wv >> 1) * 2 * TILE_DBL;
         tile_store(x, Cl, lane);
         tile_store(x + TILE_DBL, Cr, lane);
-        if (wv == 1) tile_store(xch + 5 * TILE_DBL, schur_prod<n>(Cl, lane), lane);
-        else if (ASM_WAVES * q + 4 <= N) tile_store(xch + 6 * TILE_DBL, schur_prod<n>(Cr, lane), lane);
       }
       if (!ok && lane == 0) pb.notspd[b] = 1;
       G2_ASTAMP(5);
@@ -206,14 +209,19 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
   // factor tiles taken from LDS) when that block exists, and the folding for block 4q / the next group either way
   const int j0 = ASM_WAVES * q;
   const bool next = j0 + 4 <= N;
-  Tile Sp = tile_load(xch + 4 * TILE_DBL, lane);              // S of block 4q
+  Tile Sp = tile_load(xs0, lane);                             // S of block 4q
+  // what the odd blocks owe: W_l(4q+1)^T W_l(4q+1) to block 4q, W_r(4q+3)^T W_r(4q+3) to block 4q + 4.  The products are
+  // issued here, in front of the level-2 elimination, and only masked / applied behind it: the matrix cores work through
+  // them while the pivot loop runs on the vector ALU.
+  Tile A1 = tile_zero(), R = tile_zero();
   if (j0 + 1 <= N) {
-    const Tile A1 = tile_load(xch + 5 * TILE_DBL, lane);
-#pragma unroll
-    for (int k = 0; k < 4; k++) Sp.r[k] -= A1.r[k];
+    const Tile Wl1 = tile_load(xch, lane);
+    A1 = tile_atb(Wl1, Wl1);
   }
-  Tile R = tile_zero();
-  if (next && j0 + 3 <= N) R = tile_load(xch + 6 * TILE_DBL, lane);
+  if (next && j0 + 3 <= N) {
+    const Tile Wr3 = tile_load(xch + 3 * TILE_DBL, lane);
+    R = tile_atb(Wr3, Wr3);
+  }
   if (live) {
     const int j = i;
     const Tile Wr_m = tile_load(xch + TILE_DBL, lane);       // block j - 1: W_r
@@ -236,11 +244,11 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
     tile_store_rows<n>(f + TILE_DBL, C2r, lane);
     tile_store_transposed<n>(f + 2 * TILE_DBL, V, lane);
     if (!ok && lane == 0) pb.notspd[b] = 1;
-    const Tile A2 = schur_prod<n>(C2l, lane);                // W_l(j)^T W_l(j): owed by block 4q
+    const Tile A2 = tile_atb(C2l, C2l);                      // W_l(j)^T W_l(j): owed by block 4q
 #pragma unroll
-    for (int k = 0; k < 4; k++) Sp.r[k] -= A2.r[k];
+    for (int k = 0; k < 4; k++) A1.r[k] += A2.r[k];
     if (next) {
-      const Tile B2 = schur_prod<n>(C2r, lane);              // W_r(j)^T W_r(j): owed by block 4q + 4
+      const Tile B2 = tile_atb(C2r, C2r);                    // W_r(j)^T W_r(j): owed by block 4q + 4
 #pragma unroll
       for (int k = 0; k < 4; k++) R.r[k] += B2.r[k];
       // fill-in between 4q and 4q + 4: rows of the one that level 4 eliminates
@@ -249,6 +257,10 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
     }
     G2_ASTAMP(7);
   }
+  schur_keep<n>(A1);                                          // real rows, matrix + rhs columns (as schur_sub)
+  schur_keep<n>(R);
+#pragma unroll
+  for (int k = 0; k < 4; k++) Sp.r[k] -= A1.r[k];
   tile_store_rows<n>(tiles + ((size_t)b * (N + 1) + j0) * TILE_DBL, Sp, lane);
   if (next) tile_store_rows<n>(pb.pend + ((size_t)b * groups + q) * TILE_DBL, R, lane);
 }
@@ -256,7 +268,8 @@ __global__ __launch_bounds__(64 * ASM_WAVES, LIE ? 2 : G2_ASM_MINW) void k_assem
 int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
                     const int* active, hipStream_t st) {
   const dim3 grid(hp.B * ((hp.N + ASM_WAVES) / ASM_WAVES)), block(64 * ASM_WAVES);
-  const size_t shmem = ((ASM_WAVES + 1) * (size_t)((hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I) + 7 * TILE_DBL) * sizeof(double);
+  const size_t slotd = (size_t)(hp.I + 1) * hp.RECS + hp.GPS + 24 * hp.I;
+  const size_t shmem = ((ASM_WAVES + 1) * slotd + (slotd >= TILE_DBL ? 4 : 5) * TILE_DBL) * sizeof(double);
   switch (hp.D) {
 #define G2_ASM_CASE(DD) \
   case DD:                                                                                              \

@@ -48,8 +48,11 @@ for b in (0, 33):
     if raw[4] > raw[0] > 0:
         print("   step kernel: control", int(raw[1] - raw[0]), "forward", int(raw[2] - raw[1]), "backward", int(raw[3] - raw[2]),
               "hand-over", int(raw[4] - raw[3]), "total", int(raw[4] - raw[0]))
-    for nm, sl in (("level 4", [5, 6, 13, 14, 15, 29]), ("level 16", [30, 31, 60, 61, 62, 63])):
-        v = raw[sl]
+    out2 = (C.c_ulonglong * 64)()
+    e._ck(e.lib.gpmp2mi_plan_debug_stamps(pl.h.ptr, p.B + b, out2))
+    task = np.array(list(out2), dtype=np.float64)
+    for nm, o in (("level 4", 0), ("level 8", 8), ("level 16", 16)):
+        v = task[o:o + 6]
         if np.all(v > 0):
             print(f"   one elimination task at {nm} (wave 0): loads / tile products / eliminate + W products / stores / wait at the barrier", d(v))
     fw = [raw[1]] + [raw[5 + k] for k in range(1, 9) if raw[5 + k] > 0]
