@@ -147,6 +147,23 @@ def head_commit():
         return None
 
 
+def kernels_changed_since(commit, here):
+    """True when the kernel sources (gpmp2_amd/csrc) differ between `commit` (where a stored profile was taken) and this
+    tree; later commits that only touch docs, tests or scripts do not make a profile stale.  Without git (the GPU box
+    gets the tree without .git) only an identical commit id counts as unchanged."""
+    if not commit or commit == "unknown":
+        return True
+    if here and (commit.startswith(here) or here.startswith(commit)):
+        return False
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "diff", "--quiet", commit, "HEAD", "--", "gpmp2_amd/csrc"], capture_output=True, timeout=20)
+        if out.returncode in (0, 1):
+            return out.returncode == 1
+    except Exception:
+        pass
+    return True
+
+
 def pmc_traffic():
     """HBM bytes per launch and kernel from the newest committed PMC summary under profiles/ (rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE collected in separate passes of this same command, gfx950
@@ -400,7 +417,7 @@ def main():
             tr, tr_src, tr_commit = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None, None)
             traffic = sum(tr.get(k, 0.0) for k in per) if tr else None
             here = head_commit()
-            stale = bool(tr) and (tr_commit is None or here is None or not (tr_commit.startswith(here) or here.startswith(tr_commit)))
+            stale = bool(tr) and kernels_changed_since(tr_commit, here)
             if stale:
                 print(f"bench.py: the stored traffic profile {tr_src} was taken at commit {tr_commit}, this tree is at {here}: "
                       "roofline.traffic and the per-kernel own-bytes fractions describe that commit (re-run scripts/evidence.sh)",

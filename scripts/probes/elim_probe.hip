@@ -3,6 +3,8 @@
 //   B  rtile.h rblock_* (row-per-register layout through an LDS scratch, 64-bit DPP column broadcasts)
 //   C  as B with the broadcast fused into the multiply-add (v_fmac_f64_dpp, inline asm)
 //   D  one lane per column of [S | C_l | C_r | V], multipliers through v_readlane -> SGPR operands
+//   E  tiles.h tile_eliminate_col: column operations on [S ; Vt] with v_fmac_f64_dpp, W = V C on the matrix cores (shipped)
+//   E2 as E with two pivots per step
 // build: hipcc -O3 --offload-arch=gfx950 -I gpmp2_amd/csrc scripts/probes/elim_probe.hip -o /tmp/elim_probe
 // run:   /tmp/elim_probe [waves_per_block] [reps]
 #include <hip/hip_runtime.h>
@@ -99,50 +101,7 @@ __device__ __forceinline__ bool cblock_eliminate(CBlock<n_>& R, int lane) {
   return ok;
 }
 
-// E: column operations on [S ; Vt] (Vt = I on entry) -> Vt = R^-1; W = V C by two tile products
-template <int n_>
-__device__ __forceinline__ bool tile_eliminate_col(Tile& S, Tile& Vt, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  double pv = 1.0;
-  bool ok = true;
-  static_for<0, n_>([&](auto jc) {
-    constexpr int j = decltype(jc)::value, gj = j & 3, rj = j >> 2;
-#ifdef PROBE_SWAP
-    const double rowS = bcast_row<gj>(S.r[rj]);
-#else
-    const double rowS = __shfl(S.r[rj], gj * 16 + c, 64);      // S'[j][c] in every row group
-#endif
-    const double piv = readlane_d(S.r[rj], gj * 16 + j);
-    const double ninv = -fast_rcp(piv);
-    const double nf = (c > j && c < n_) ? rowS * ninv : 0.0;   // -f_c; columns <= j and the padding stay untouched
-    static_for<0, 4>([&](auto kc) {
-      constexpr int k = decltype(kc)::value;
-      if constexpr (k >= rj) {   // rows of S at or below the pivot's register
-        double t = S.r[k];
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(nf), "n"(j));
-        S.r[k] = t;
-      }
-      if constexpr (k <= rj) {   // Vt is upper triangular: column j lives in rows <= j
-        double t = Vt.r[k];
-        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(nf), "n"(j));
-        Vt.r[k] = t;
-      }
-    });
-  });
-  // the pivots are what is left on the diagonal: column c needs S[c][c] (row group c & 3, register c >> 2)
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const double dgn = __shfl(S.r[k], (c & 3) * 16 + c, 64);
-    pv = ((c >> 2) == k && c < n_) ? dgn : pv;
-  }
-  ok = !(pv <= 0.0) && (pv == pv);
-  ok = __all(ok);
-  const double rs = fast_rsqrt(pv);
-#pragma unroll
-  for (int k = 0; k < 4; k++) Vt.r[k] *= rs;
-  return ok;
-}
-
+// E: the shipped column form, tiles.h tile_eliminate_col (column operations on [S ; Vt], W = V C by two tile products)
 // E2: as E, two pivots per step.  Both multiplier rows are formed from the state BEFORE the pair (row j and row j + 1
 // broadcast together, the 2x2 pivot block read in one go), so the cross-lane and reciprocal latencies are paid n / 2
 // times; the two rank-1 column updates then run back to back.
