@@ -23,17 +23,21 @@ namespace g2 {
 #ifdef G2_STAMPS
 #define G2_STAMP(k)                                                          \
   do {                                                                       \
-    if (tid == 0 && (k) < 64 && pb.iters[b] == G2_STAMP_ITER) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if (tid == 0 && (k) < 64 && g2_son) pb.stamps[(size_t)b * 64 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// (the gate is read once per function: a stamp then costs one s_memtime and one store, not a load as well)
+#define G2_STAMP_DECL const bool g2_son = pb.iters[b] == G2_STAMP_ITER
 #else
 #define G2_STAMP(k) do {} while (0)
+#define G2_STAMP_DECL do {} while (0)
 #endif
-#ifdef G2_STAMPS
-// phases of ONE elimination task (wave 0 of the workgroup) at levels 4, 8 and 16: second stamp region of the plan (row
+#ifdef G2_TSTAMPS
+// -DG2_TSTAMPS on top of -DG2_STAMPS (`make stamps STAMPFLAGS=-DG2_TSTAMPS`; these stamps and the waits that delimit their
+// phases lengthen a level by ~30 %): phases of ONE elimination task (wave 0 of the workgroup) at levels 4, 8 and 16: second stamp region of the plan (row
 // B + b), slots 0..5 / 8..13 / 16..21
 #define G2_TSTAMP(q)                                                                                     \
   do {                                                                                                   \
-    if (w == 0 && lane == 0 && idx == 0 && pb.iters[b] == G2_STAMP_ITER && (h == 4 || h == 8 || h == 16)) \
+    if (w == 0 && lane == 0 && idx == 0 && g2_son && (h == 4 || h == 8 || h == 16)) \
       pb.stamps[((size_t)gridDim.x + b) * 64 + (h == 4 ? 0 : h == 8 ? 8 : 16) + (q)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
@@ -344,6 +348,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   double* tiles = pb.tiles + (size_t)b * (N + 1) * TILE_DBL;  // S tile of every block
   double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;  // per block: Wl, Wr, V
   bool ok = true;
+  G2_STAMP_DECL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
   // levels 1 and 2 were done by k_assemble (level 2 only when it is not the final one, N >= 2), including
@@ -392,7 +397,7 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
         if (ep) Wl_p = tile_load_rows<n>(facp(jp, 0), lane);
         if (cp) Wr_p = tile_load_rows<n>(facp(jp, 1), lane);
       }
-#ifdef G2_STAMPS
+#ifdef G2_TSTAMPS
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
       G2_TSTAMP(1);
@@ -408,13 +413,13 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
         tile_store_rows<n>(tiles + (size_t)j * TILE_DBL, S, lane);
         continue;
       }
-#ifdef G2_STAMPS
+#ifdef G2_TSTAMPS
       asm volatile("" : "+v"(S.r[0]), "+v"(Cl.r[0]), "+v"(Cr.r[0]));
 #endif
       G2_TSTAMP(2);
       Tile V;
       ok = tile_eliminate_cv<n>(S, Cl, Cr, V, lane) && ok;
-#ifdef G2_STAMPS
+#ifdef G2_TSTAMPS
       asm volatile("" : "+v"(V.r[0]), "+v"(Cl.r[0]), "+v"(Cr.r[0]));
 #endif
       G2_TSTAMP(3);
@@ -445,6 +450,7 @@ template <int n>
 __device__ __forceinline__ void cr_backward(const PlanBuffers& pb, int b, int N, int tid, double* xs, int hmin = 1) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
   const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+  G2_STAMP_DECL;
   int hfinal = 1;
   while (hfinal <= N) hfinal <<= 1;
   // the factor tiles of a wavefront's first task of a level do not depend on the level above: they are requested
@@ -500,6 +506,7 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
   double* xs = smem;                       // [N+1][16] solution of each block
   double* red = smem + (size_t)(N + 1) * 16;  // [CR_WAVES] reduction scratch
   int* flags = reinterpret_cast<int*>(red + CR_WAVES);  // [0] decision, [1] not-spd
+  G2_STAMP_DECL;
 
   G2_STAMP(0);
   // ---- graph error at `cur`: fixed-order sum of the per-block partials written by k_assemble,
