@@ -1058,10 +1058,13 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.fixed_iters = o.fixed_iterations;
   P.end_conf_prior_off = o.end_conf_prior_off ? 1 : 0;
   {
-    // sphere-split linearization for fixed-base arms (k_linearize NSPLIT = 2); GPMP2MI_LIN_SPLIT=1 / 2 forces either form
+    // sphere-split linearization for fixed-base arms: four wavefronts per 64 points sharing one walk of the chain
+    // (k_linearize_arm) up to 256 trajectories, two wavefronts that each walk it (k_linearize NSPLIT = 2) above --
+    // measured (scripts/probes/split_sweep.sh): 14.4 / 16.8 / 22.5 / 35.5 / 59.3 us against 17.6 / 18.7 / 24.2 / 35.6 /
+    // 58.1 us at 32 / 64 / 128 / 256 / 512 trajectories.  GPMP2MI_LIN_SPLIT=1 / 2 / 4 forces a form.
     const char* e = getenv("GPMP2MI_LIN_SPLIT");
-    P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? 2 : 1;
-    if (e && (e[0] == '1' || e[0] == '2')) P.lin_split = e[0] - '0';
+    P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? (B <= 256 ? 4 : 2) : 1;
+    if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) P.lin_split = e[0] - '0';
   }
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);

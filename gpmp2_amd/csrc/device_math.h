@@ -37,7 +37,6 @@ __device__ __forceinline__ bool sdf3_lookup(const SdfDev& s, double px, double p
   const double col = div_cell(px - s.ox, s.cell, s.inv_cell), row = div_cell(py - s.oy, s.cell, s.inv_cell),
                z = div_cell(pz - s.oz, s.cell, s.inv_cell);
   const double lr = floor(row), lc = floor(col), lz = floor(z);
-  const double hr = lr + 1.0, hc = lc + 1.0, hz = lz + 1.0;
   const int lri = (int)lr, lci = (int)lc, lzi = (int)lz;
 #ifdef G2_SDF_PLAIN
   // A/B build only: the same lookup from the plain [z][y][x] field (8 B per voxel, 1/8 of the memory): eight 8-B
@@ -54,17 +53,20 @@ __device__ __forceinline__ bool sdf3_lookup(const SdfDev& s, double px, double p
   const double v000 = a0.x, v010 = a0.y, v100 = a1.x, v110 = a1.y;  // (row,col,z): vRCZ
   const double v001 = a2.x, v011 = a2.y, v101 = a3.x, v111 = a3.y;
 #endif
-  const double wr1 = row - lr, wr0 = hr - row, wc1 = col - lc, wc0 = hc - col, wz1 = z - lz,
-               wz0 = hz - z;
-  dist = wr0 * wc0 * wz0 * v000 + wr1 * wc0 * wz0 * v100 + wr0 * wc1 * wz0 * v010 +
-         wr1 * wc1 * wz0 * v110 + wr0 * wc0 * wz1 * v001 + wr1 * wc0 * wz1 * v101 +
-         wr0 * wc1 * wz1 * v011 + wr1 * wc1 * wz1 * v111;
-  const double g_row = wc0 * wz0 * (v100 - v000) + wc1 * wz0 * (v110 - v010) +
-                       wc0 * wz1 * (v101 - v001) + wc1 * wz1 * (v111 - v011);
-  const double g_col = wr0 * wz0 * (v010 - v000) + wr1 * wz0 * (v110 - v100) +
-                       wr0 * wz1 * (v011 - v001) + wr1 * wz1 * (v111 - v101);
-  const double g_z = wr0 * wc0 * (v001 - v000) + wr1 * wc0 * (v101 - v100) +
-                     wr0 * wc1 * (v011 - v010) + wr1 * wc1 * (v111 - v110);
+  // Trilinear value and gradient in nested form: interpolate along the row, then the column, then z.  The reference
+  // (SignedDistanceField.h:110-167) writes the same polynomial as eight weighted corners and three sums of four weighted
+  // differences (76 operations); nested, the value takes 7 interpolations and the three gradients reuse their
+  // differences (22 operations).  Results differ from the corner form by rounding only (a few ulp).
+  const double tr = row - lr, tc = col - lc, tz = z - lz;
+  const double d00 = v100 - v000, d10 = v110 - v010, d01 = v101 - v001, d11 = v111 - v011;   // d_cz = v1cz - v0cz
+  const double a00 = fma(tr, d00, v000), a10 = fma(tr, d10, v010), a01 = fma(tr, d01, v001), a11 = fma(tr, d11, v011);
+  const double e0 = a10 - a00, e1 = a11 - a01;                                                // along the column
+  const double b0 = fma(tc, e0, a00), b1 = fma(tc, e1, a01);
+  const double g_z = b1 - b0;
+  dist = fma(tz, g_z, b0);
+  const double g_col = fma(tz, e1 - e0, e0);
+  const double r0 = fma(tc, d10 - d00, d00), r1 = fma(tc, d11 - d01, d01);
+  const double g_row = fma(tz, r1 - r0, r0);
   // (g_idx / cell_size of SignedDistanceField.h:97 as a multiplication by the stored reciprocal: <= 1 ulp)
   gx = g_col * s.inv_cell;
   gy = g_row * s.inv_cell;
@@ -76,15 +78,18 @@ __device__ __forceinline__ bool sdf2_lookup(const SdfDev& s, double px, double p
                                             double& gx, double& gy) {
   if (px < s.ox || px > s.hix || py < s.oy || py > s.hiy) return false;
   const double col = div_cell(px - s.ox, s.cell, s.inv_cell), row = div_cell(py - s.oy, s.cell, s.inv_cell);
-  const double lr = floor(row), lc = floor(col), hr = lr + 1.0, hc = lc + 1.0;
+  const double lr = floor(row), lc = floor(col);
   const int lri = (int)lr, lci = (int)lc;
   const double2* c = reinterpret_cast<const double2*>(s.cells + ((size_t)lri * s.nx + lci) * 4);
   const double2 a0 = c[0], a1 = c[1];
   const double v00 = a0.x, v01 = a0.y, v10 = a1.x, v11 = a1.y;  // vRC
-  dist = (hr - row) * (hc - col) * v00 + (row - lr) * (hc - col) * v10 +
-         (hr - row) * (col - lc) * v01 + (row - lr) * (col - lc) * v11;
-  const double g_row = (hc - col) * (v10 - v00) + (col - lc) * (v11 - v01);
-  const double g_col = (hr - row) * (v01 - v00) + (row - lr) * (v11 - v10);
+  // bilinear value and gradient in nested form (see sdf3_lookup; PlanarSDF.h:80-116 writes the four weighted corners)
+  const double tr = row - lr, tc = col - lc;
+  const double d0 = v10 - v00, d1 = v11 - v01;          // along the row, at column 0 / 1
+  const double i0 = fma(tr, d0, v00), i1 = fma(tr, d1, v01);
+  const double g_col = i1 - i0;
+  dist = fma(tc, g_col, i0);
+  const double g_row = fma(tc, d1 - d0, d0);
   gx = g_col * s.inv_cell;
   gy = g_row * s.inv_cell;
   return true;
@@ -140,10 +145,8 @@ __device__ __forceinline__ void frame_from_3x4(const double* M, Frame& F) {
 
 // F <- F * Rz(theta) * Tz(d) * Tx(a) * Rx(alpha)   (Arm::getJointTrans, kinematics/Arm.h:93-98,
 // link_trans_notheta_ kinematics/Arm.cpp:23-27)
-__device__ __forceinline__ void dh_advance(Frame& F, double theta, double a, double d, double ca,
-                                           double sa) {
-  double s, c;
-  sincos(theta, &s, &c);
+__device__ __forceinline__ void dh_advance_sc(Frame& F, double s, double c, double a, double d, double ca,
+                                              double sa) {
 #pragma unroll
   for (int i = 0; i < 3; i++) {
     const double n0 = c * F.c0[i] + s * F.c1[i];
@@ -154,6 +157,12 @@ __device__ __forceinline__ void dh_advance(Frame& F, double theta, double a, dou
     F.c1[i] = ca * n1 + sa * z;
     F.c2[i] = -sa * n1 + ca * z;
   }
+}
+__device__ __forceinline__ void dh_advance(Frame& F, double theta, double a, double d, double ca,
+                                           double sa) {
+  double s, c;
+  sincos(theta, &s, &c);
+  dh_advance_sc(F, s, c, a, d, ca, sa);
 }
 
 // Generic visitor-style forward kinematics over a sphere model.
@@ -271,22 +280,22 @@ struct Kin {
   }
 
   // f(s, p, tag) for every body sphere in sorted (= link) order, with its world centre p
-  // sub / nsub: visit only the spheres s with s % nsub == sub; nsub a power of 2.
+  // sub / nsub: visit only the spheres s with s % nsub == sub (both uniform over the wavefront).
   template <class F>
   __device__ __forceinline__ static void walk(const RobotDev& R, const double (&q)[DOF], Axes& A, F&& f,
                                               int sub = 0, int nsub = 1) {
-    const int smask = nsub - 1;
+    auto mine = [&](int s) { return nsub == 1 || (s % nsub) == sub; };
     if constexpr (KIND == GPMP2MI_ROBOT_POINT) {
       // PointRobot::forwardKinematics  kinematics/PointRobot.cpp:15-49
       for (int s = 0; s < R.nr_spheres; s++) {
-        if ((s & smask) != sub) continue;
+        if (!mine(s)) continue;
         const double p[3] = {q[0] + R.sph_c[3 * s], q[1] + R.sph_c[3 * s + 1], R.sph_c[3 * s + 2]};
         f(s, p, ColTag<2, 0>{});
       }
     } else {
       walk_links(R, q, A, [&](int link, const Frame& Fr, auto tag) {
         for (int s = R.link_first[link]; s < R.link_first[link + 1]; s++) {
-          if ((s & smask) != sub) continue;
+          if (!mine(s)) continue;
           double p[3];
 #pragma unroll
           for (int i = 0; i < 3; i++)

@@ -85,16 +85,15 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
     x0[k] = (i > 0) ? z0[k] : 0.0;
     v0[k] = (i > 0) ? z0[D + k] : 0.0;
   }
-  double Mlie[4][9];
-  bool lie_interp = false;
   if (unary) {
 #pragma unroll
     for (int k = 0; k < D; k++) q[k] = x1[k];
   } else {
     const GpCoef c = P.coef[j];
     if constexpr (K::BASE == 3) {
-      lie_interpolate<D>(c, x0, v0, x1, v1, q, Mlie);   // GaussianProcessInterpolatorPose2Vector
-      lie_interp = true;
+      // GaussianProcessInterpolatorPose2Vector: the configuration now, the pose blocks of its four Jacobians when the
+      // record is stored (36 doubles that would otherwise stay live across the whole sphere loop)
+      lie_interpolate<D>(c, x0, v0, x1, v1, q, nullptr);
     } else {
 #pragma unroll
       for (int k = 0; k < D; k++) q[k] = c.l11 * x0[k] + c.l12 * v0[k] + c.p11 * x1[k] + c.p12 * v1[k];
@@ -184,10 +183,26 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
     for (int k = 0; k < D; k++) rv[NG + k] = gv[k] * w;
     rv[NG + D] = e * w;
     if constexpr (K::BASE == 3) {  // pose blocks of the four interpolation Jacobians
+      double Mlie[4][9];
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
-        for (int t = 0; t < 9; t++) rv[NG + D + 1 + m * 9 + t] = lie_interp ? Mlie[m][t] : 0.0;
+        for (int t = 0; t < 9; t++) Mlie[m][t] = 0.0;
+      if (!unary) {
+        double a0[D], b0[D], a1[D], b1[D], qq[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+          a1[k] = z1[k];
+          b1[k] = z1[D + k];
+          a0[k] = z0[k];
+          b0[k] = z0[D + k];
+        }
+        lie_interpolate<D>(P.coef[j], a0, b0, a1, b1, qq, Mlie);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) rv[NG + D + 1 + m * 9 + t] = Mlie[m][t];
     }
     rv[RECL] = 0.0;
     double2* rb = reinterpret_cast<double2*>(rec + ((size_t)b * P.Ppad + p) * P.RECS);
@@ -271,6 +286,240 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k_linearize for fixed-base arms, round 3: NW wavefronts per 64 evaluation points that SHARE one walk of the
+// kinematic chain instead of replicating it.
+//   phase 1  every wavefront interpolates the point's configuration (replicated: 28 loads, 28 FMAs) and takes the
+//            sin / cos of the joints j % NW == its index -> LDS
+//   phase 2  wavefront 0 walks the chain once (AD dependent frame advances) and leaves, per link, the columns c0, c2
+//            and the origin t of its frame in LDS (9 doubles per lane and link; c1 = c2 x c0 is recomputed where a
+//            sphere centre needs it).  Axis and origin of joint k are c2 and t of frame k - 1 (the base frame for k = 0)
+//   phase 3  wavefront w visits the spheres s % NW == w: centre from its link's frame, SDF lookup, hinge, and for the
+//            active lanes the Jacobian columns z_k x (p - o_k) of the joints below the link, accumulated as before
+//   phase 4  partial records summed over the wavefronts in a fixed tree order through LDS (the frames' bytes), wavefront
+//            0 stores the record while the last wavefront evaluates the GP prior
+// Against the two-wavefront split above (both wavefronts walk the chain and keep all joint axes in registers, 252
+// VGPRs, two wavefronts per SIMD) the dependent chain of a wavefront is sin/cos of two joints + 4 spheres instead of
+// 7 joints + 8 spheres, and 168 VGPRs leave room for three wavefronts per SIMD: 640 workgroups x 4 wavefronts of the
+// 64-restart batch are resident at once.
+template <int AD, int SDIM, int NW>
+__global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __restrict__ Rg, SdfDev sdf,
+                                                               const PlanParams* __restrict__ pp, PlanBuffers pb,
+                                                               const double* __restrict__ traj, int bufsel,
+                                                               const int* __restrict__ active) {
+  static_assert(NW == 2 || NW == 4, "tree reduction below");
+  constexpr int D = AD, n = 2 * D, NG = D * (D + 1) / 2, RV = NG + D + 1;
+  constexpr int FR = 9;                                  // doubles per lane and link: c0, c2, t
+  constexpr int ROWS_F = FR * AD, ROWS_SC = 2 * AD;
+  constexpr int ROWS_P = (NW / 2) * RV;                  // partial records: NW / 2 buffers
+  constexpr int ROWS = (ROWS_F + ROWS_SC > ROWS_P) ? ROWS_F + ROWS_SC : ROWS_P;
+  const PlanParams& P = *pp;
+  const int nchunk = P.Ppad / 64;
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x - b * nchunk;
+  if (active && !active[b]) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  double* __restrict__ rec = rec_of(pb, pb.which[b], bufsel);
+  double* __restrict__ gpu = gpu_of(pb, pb.which[b], bufsel);
+  G2_LSTAMP(0);
+  __shared__ RobotDev R;
+  __shared__ double buf[ROWS][64];                       // [0, ROWS_F) frames, [ROWS_F, ROWS_F + ROWS_SC) sin / cos; later the partial records
+  constexpr int NT = 64 * NW, RN = sizeof(RobotDev) / 4, RPT = (RN + NT - 1) / NT;
+  int rtmp[RPT];
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+    const int idx = threadIdx.x + NT * u;
+    rtmp[u] = idx < RN ? reinterpret_cast<const int*>(Rg)[idx] : 0;
+  }
+  const int p_raw = chunk * 64 + lane;
+  const int p = min(p_raw, P.P - 1);  // tail lanes shadow the last point, their stores are predicated
+  const int N = P.N, I = P.I;
+  int i = 0, j = I;
+  if (p > 0) {
+    const int t = p - 1;
+    i = 1 + t / (I + 1);
+    j = t - (i - 1) * (I + 1);
+  }
+  const bool unary = (j == I);
+  const double* z1 = traj + ((size_t)b * (N + 1) + i) * n;          // state i
+  const double* z0 = (i > 0) ? z1 - n : z1;                          // state i-1 (only used if i > 0)
+  {
+    double q[D];
+    if (unary) {
+#pragma unroll
+      for (int k = 0; k < D; k++) q[k] = z1[k];
+    } else {
+      const GpCoef c = P.coef[j];
+#pragma unroll
+      for (int k = 0; k < D; k++) q[k] = c.l11 * z0[k] + c.l12 * z0[D + k] + c.p11 * z1[k] + c.p12 * z1[D + k];
+    }
+    // sin / cos of this wavefront's joints (the joint bias straight from the model in HBM: a uniform scalar load)
+#pragma unroll
+    for (int k = 0; k < AD; k++) {
+      if (k % NW != wv) continue;
+      double sn, cs;
+      sincos(q[k] + Rg->bias[k], &sn, &cs);
+      buf[ROWS_F + 2 * k][lane] = sn;
+      buf[ROWS_F + 2 * k + 1][lane] = cs;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < RPT; u++) {
+    const int idx = threadIdx.x + NT * u;
+    if (idx < RN) reinterpret_cast<int*>(&R)[idx] = rtmp[u];
+  }
+  __syncthreads();
+  G2_LSTAMP(1);
+  if (wv == 0) {
+    Frame F;
+    frame_from_3x4(R.base, F);  // world_T_base
+    static_for<0, AD>([&](auto jc) {
+      constexpr int k = decltype(jc)::value;
+      const double sn = buf[ROWS_F + 2 * k][lane], cs = buf[ROWS_F + 2 * k + 1][lane];
+      dh_advance_sc(F, sn, cs, R.a[k], R.d[k], R.ca[k], R.sa[k]);
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        buf[FR * k + t][lane] = F.c0[t];
+        buf[FR * k + 3 + t][lane] = F.c2[t];
+        buf[FR * k + 6 + t][lane] = F.t[t];
+      }
+    });
+  }
+  __syncthreads();
+  G2_LSTAMP(2);
+  double G[NG], gv[D], e = 0.0;
+#pragma unroll
+  for (int k = 0; k < NG; k++) G[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < D; k++) gv[k] = 0.0;
+  if (!(P.obs_skip_first && p == 0)) {
+    const double eps = P.eps;
+    static_for<0, AD>([&](auto jc) {
+      constexpr int L = decltype(jc)::value, NC = L + 1;     // link L: the joints 0 .. L move it
+      for (int s = R.link_first[L]; s < R.link_first[L + 1]; s++) {
+        if (s % NW != wv) continue;
+        double c0[3], c2[3], o[3], pt[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+          c0[t] = buf[FR * L + t][lane];
+          c2[t] = buf[FR * L + 3 + t][lane];
+          o[t] = buf[FR * L + 6 + t][lane];
+        }
+        const double c1[3] = {c2[1] * c0[2] - c2[2] * c0[1], c2[2] * c0[0] - c2[0] * c0[2], c2[0] * c0[1] - c2[1] * c0[0]};
+        const double cx = R.sph_c[3 * s], cy = R.sph_c[3 * s + 1], cz = R.sph_c[3 * s + 2];
+#pragma unroll
+        for (int t = 0; t < 3; t++) pt[t] = o[t] + c0[t] * cx + c1[t] * cy + c2[t] * cz;
+        double hx, hy, hz;
+        const double r = hinge_obstacle<SDIM>(sdf, pt[0], pt[1], pt[2], R.sph_r[s] + eps, hx, hy, hz);
+        // inactive hinge (or out of the field): zero residual row, nothing to accumulate
+        if (hx == 0.0 && hy == 0.0 && hz == 0.0 && r == 0.0) continue;
+        double Jr[NC];
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+          double zx, zy, zz, ox, oy, oz;
+          if (k == 0) {   // joint 0 sits in the base frame: R.base rows are (c0 c1 c2 t) per coordinate
+            zx = R.base[2]; zy = R.base[6]; zz = R.base[10];
+            ox = R.base[3]; oy = R.base[7]; oz = R.base[11];
+          } else {
+            zx = buf[FR * (k - 1) + 3][lane]; zy = buf[FR * (k - 1) + 4][lane]; zz = buf[FR * (k - 1) + 5][lane];
+            ox = buf[FR * (k - 1) + 6][lane]; oy = buf[FR * (k - 1) + 7][lane]; oz = buf[FR * (k - 1) + 8][lane];
+          }
+          const double rx = pt[0] - ox, ry = pt[1] - oy, rz = pt[2] - oz;
+          const double Jx = zy * rz - zz * ry, Jy = zz * rx - zx * rz, Jz = zx * ry - zy * rx;   // z_k x (p - o_k)
+          Jr[k] = hx * Jx + hy * Jy + (SDIM == 3 ? hz * Jz : 0.0);
+        }
+        e += r * r;
+#pragma unroll
+        for (int k = 0; k < NC; k++) {
+          gv[k] += Jr[k] * r;
+#pragma unroll
+          for (int k2 = k; k2 < NC; k2++) G[k * D - (k * (k - 1)) / 2 + (k2 - k)] += Jr[k] * Jr[k2];
+        }
+      }
+    });
+  }
+  G2_LSTAMP(3);
+  // partial records -> wavefront 0, fixed order: (w0 + w2) + (w1 + w3)
+  __syncthreads();   // every wavefront is done with the frames: their bytes now take the partial records
+  auto put = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < NG; k++) buf[slot * RV + k][lane] = G[k];
+#pragma unroll
+    for (int k = 0; k < D; k++) buf[slot * RV + NG + k][lane] = gv[k];
+    buf[slot * RV + NG + D][lane] = e;
+  };
+  auto add = [&](int slot) {
+#pragma unroll
+    for (int k = 0; k < NG; k++) G[k] += buf[slot * RV + k][lane];
+#pragma unroll
+    for (int k = 0; k < D; k++) gv[k] += buf[slot * RV + NG + k][lane];
+    e += buf[slot * RV + NG + D][lane];
+  };
+  if constexpr (NW == 4) {
+    if (wv >= 2) put(wv - 2);
+    __syncthreads();
+    if (wv < 2) add(wv);
+    if (wv == 1) put(1);      // (slot 1 was read by wavefront 1 alone)
+    __syncthreads();
+    if (wv == 0) add(1);
+  } else {
+    if (wv == 1) put(0);
+    __syncthreads();
+    if (wv == 0) add(0);
+  }
+  const bool store_ok = p_raw < P.P;
+  G2_LSTAMP(13);
+  if (wv == 0) {
+    // point-major record: this lane's REC values are one contiguous run, stored in 16-B pieces
+    const double w = P.obs_w;
+    constexpr int RECL = NG + D + 1;
+    double rv[RECL + 1];
+#pragma unroll
+    for (int k = 0; k < NG; k++) rv[k] = G[k] * w;
+#pragma unroll
+    for (int k = 0; k < D; k++) rv[NG + k] = gv[k] * w;
+    rv[NG + D] = e * w;
+    rv[RECL] = 0.0;
+    double2* rb = reinterpret_cast<double2*>(rec + ((size_t)b * P.Ppad + p) * P.RECS);
+#pragma unroll
+    for (int k = 0; k < (RECL + 1) / 2; k++)
+      if (store_ok) rb[k] = double2{rv[2 * k], rv[2 * k + 1]};
+  }
+  G2_LSTAMP(14);
+  // GP prior of the interval ending at state i: GaussianProcessPriorLinear (gp/GaussianProcessPriorLinear.h:57-83),
+  // r = Phi z_{i-1} - z_i, u = Q^-1 r (Q^-1 = B(dt) (x) Qc^-1), energy r^T u -- as in k_linearize above
+  if (unary && i > 0 && store_ok && wv == NW - 1) {
+    double rx[D], rv[D], sx[D], sv[D];
+    double* gb = gpu + ((size_t)b * P.Npad + i) * P.GPS;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      rx[k] = z0[k] + P.delta_t * z0[D + k] - z1[k];
+      rv[k] = z0[D + k] - z1[D + k];
+    }
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      double ax = 0, av = 0;
+#pragma unroll
+      for (int m = 0; m < D; m++) {
+        ax += P.Qc_inv[k * D + m] * rx[m];
+        av += P.Qc_inv[k * D + m] * rv[m];
+      }
+      sx[k] = ax;
+      sv[k] = av;
+    }
+    double en = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; k++) {
+      const double ux = P.Winv[0] * sx[k] + P.Winv[1] * sv[k];
+      const double uv = P.Winv[2] * sx[k] + P.Winv[3] * sv[k];
+      gb[k] = ux;
+      gb[D + k] = uv;
+      en += rx[k] * ux + rv[k] * uv;
+    }
+    gb[n] = en;
+  }
+  G2_LSTAMP(15);
+}
+
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
                      const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
                      hipStream_t st) {
@@ -278,7 +527,14 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   // workgroup (NSPLIT = 2, see the kernel).  A variant that kept 4-8 SDF cells in flight per lane was no faster
   // (DESIGN.md section 4).
   const dim3 grid(hp.B * (hp.Ppad / 64));
-  if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
+  if (hp.lin_split == 4 && h.kind == GPMP2MI_ROBOT_ARM) {
+    const dim3 block(256);
+    if (sdf.dim == 3) {
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 3, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    } else {
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 2, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+    }
+  } else if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(128);
     if (sdf.dim == 3) {
       G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize<GPMP2MI_ROBOT_ARM, AD_, 0, 3, 2><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
