@@ -1038,6 +1038,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   const char* wd_env = getenv("GPMP2MI_WIDE_DENSE");
   const bool dense_path = dense_only || (wide && wd_env && wd_env[0] == '1');   // dense block solver: no split tail
   P.split_back = (!dense_path && P.N >= 16) ? 1 : 0;   // the finish kernels take groups of 8 blocks (levels 4, 2, 1)
+  if (const char* e = getenv("GPMP2MI_SPLIT_BACK")) if (e[0] == '0') P.split_back = 0;   // A/B: whole back-substitution in the step kernel
   P.spart_groups = (P.N + 8) / 8;
   // wide blocks: the first forward levels (2, 4) run chip-wide when they are not among the last two of the tree
   P.wide_h0 = 2;

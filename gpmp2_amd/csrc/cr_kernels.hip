@@ -509,6 +509,9 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
   G2_STAMP_DECL;
 
   G2_STAMP(0);
+  // what the step control below needs from HBM is requested before the error sum, not after its barrier
+  const int it = pb.iters[b];
+  const double prev = pb.prev_err[b];
   // ---- graph error at `cur`: fixed-order sum of the per-block partials written by k_assemble,
   // then the gpmp2::optimize control flow
   if (w == 0) {
@@ -524,7 +527,6 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
   if (tid == 0) {
     const double new_err = red[0];
     int decision = 0;  // 0 iterate, 1 stop(result = cur), 2 stop(result = last)
-    const int it = pb.iters[b];
     double* tr = pb.trace + (size_t)b * (P.max_iter + 1);
     if (it <= P.max_iter) tr[it] = new_err;
     if (pass == 0) {
@@ -535,7 +537,6 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
     } else if (P.fixed_iters > 0) {
       if (it >= P.fixed_iters) { decision = 1; pb.status[b] = GPMP2MI_TRAJ_MAX_ITER; }
     } else {
-      const double prev = pb.prev_err[b];
       const bool conv = check_convergence(P.rel_thresh, P.abs_tol, P.err_tol, prev, new_err);
       if (it < P.max_iter && !conv) {
         pb.prev_err[b] = new_err;
