@@ -1391,9 +1391,13 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
     // pass k, so the GPU never waits for the host.  When pass k turns out to have finished every
     // trajectory, the already enqueued pass k+1 is a no-op (all workgroups exit on active[b] == 0).
     const int max_pass = iter_cap + 1;
-    for (int pass = 0; pass < max_pass; pass++) {
-      p->timer.begin("linearize", st);
-      G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
+    // How far the host runs ahead.  "pass" (rounds 1-2): pass k+1 is enqueued whole before the count of pass k-1 is
+    // looked at, so one idle pass (four empty kernels, ~18 us) follows the last active one.  "lin": only the
+    // linearization of pass k+1 is enqueued ahead; its other three kernels follow once the count of pass k is in, which
+    // the host learns while the GPU still has the finish kernel of pass k and that linearization (~23 us) to run -- the
+    // idle tail shrinks to one empty kernel.
+    static const bool ahead_lin = [] { const char* e = getenv("GPMP2MI_GN_LOOKAHEAD"); return !(e && e[0] == 'p'); }();
+    auto enqueue_rest = [&](int pass) -> int {
       if (P.fixed_iters > 0 && pass == P.fixed_iters) {
         // closing pass of a fixed-iteration run: nothing is solved any more, only the error of the final values
         p->timer.begin("final_error", st);
@@ -1408,11 +1412,33 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
         p->timer.begin("finish_step", st);
         G2_TRY(launch_finish_step(P, pb, pass, st));
       }
-      p->timer.close(st);
-      if (pass >= 1) {
+      return GPMP2MI_OK;
+    };
+    if (ahead_lin) {
+      p->timer.begin("linearize", st);
+      G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
+      for (int pass = 0; pass < max_pass; pass++) {
+        G2_TRY(enqueue_rest(pass));
+        if (pass + 1 == max_pass) break;
+        p->timer.begin("linearize", st);
+        G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));   // of pass + 1, ahead of the count
+        p->timer.close(st);
         int cnt = 0;
-        G2_TRY(wait_pass_count(p, pass - 1, st, &cnt));
+        G2_TRY(wait_pass_count(p, pass, st, &cnt));
         if (cnt == 0) break;
+      }
+      p->timer.close(st);
+    } else {
+      for (int pass = 0; pass < max_pass; pass++) {
+        p->timer.begin("linearize", st);
+        G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
+        G2_TRY(enqueue_rest(pass));
+        p->timer.close(st);
+        if (pass >= 1) {
+          int cnt = 0;
+          G2_TRY(wait_pass_count(p, pass - 1, st, &cnt));
+          if (cnt == 0) break;
+        }
       }
     }
   } else {
