@@ -179,7 +179,9 @@ def pmc_traffic():
         out = {}
         for name, v in d.get("kernels", {}).items():
             if name.startswith("k_"):
-                out[name.split("<")[0][2:]] = v["hbm_bytes_per_launch_corrected"]
+                key = name.split("<")[0][2:]
+                key = {"linearize_arm": "linearize"}.get(key, key)   # the fixed-base-arm form of the same pass stage
+                out[key] = out.get(key, 0.0) + v["hbm_bytes_per_launch_corrected"]
         if out:
             return out, os.path.basename(f), d.get("commit")
     return None, None, None
