@@ -1396,7 +1396,8 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
     // linearization of pass k+1 is enqueued ahead; its other three kernels follow once the count of pass k is in, which
     // the host learns while the GPU still has the finish kernel of pass k and that linearization (~23 us) to run -- the
     // idle tail shrinks to one empty kernel.
-    static const bool ahead_lin = [] { const char* e = getenv("GPMP2MI_GN_LOOKAHEAD"); return !(e && e[0] == 'p'); }();
+    const char* ahead_env = getenv("GPMP2MI_GN_LOOKAHEAD");
+    const bool ahead_lin = !(ahead_env && ahead_env[0] == 'p');
     auto enqueue_rest = [&](int pass) -> int {
       if (P.fixed_iters > 0 && pass == P.fixed_iters) {
         // closing pass of a fixed-iteration run: nothing is solved any more, only the error of the final values

@@ -629,3 +629,65 @@ def test_every_block_width_of_the_one_tile_path(engine, oracle, D, opt):
     p = problems.Problem(f"planar arm, {D} joints", model, [d.origin_x, d.origin_y], d.cell_size, field, st, start, z, end,
                          z.copy(), init)
     check_contract(engine, oracle, p, label=p.name, final_error_rtol=1e-8)
+
+
+@pytest.mark.parametrize("case", ["wam3d", "planar3", "planar5"])
+def test_every_linearization_form_of_fixed_base_arms(engine, oracle, monkeypatch, case):
+    """Fixed-base arms have three forms of the linearization kernel: one wavefront per 64 points (GPMP2MI_LIN_SPLIT=1), two
+    wavefronts that both walk the chain (2; the default above 256 trajectories) and four that share one walk through LDS
+    (4: k_linearize_arm, the default up to 256).  All three against the oracle's normal equations, and against each other."""
+    import gpmp2_amd as g
+    from gpmp2_amd import datasets
+    from gpmp2_amd.settings import TrajOptimizerSetting
+    from gpmp2_amd.trajutils import initArmTrajStraightLine
+    rng = np.random.default_rng(12)
+    if case == "wam3d":
+        p = problems.wam_restarts(B=3, total_step=11, obs_check_inter=4, opt="GN", sdf="40")
+        traj = p.init + 0.05 * rng.normal(size=p.init.shape)
+    else:
+        D = int(case[-1])
+        arm = g.Arm(D, [0.9 / D] * D, [0.0] * D, [0.0] * D)
+        model = g.ArmModel(arm, [g.BodySphere(l, 0.05, (-0.45 / D * k, 0, 0)) for l in range(D) for k in (0, 1)])
+        d = datasets.generate2Ddataset("TwoObstaclesDataset")
+        field = datasets.signedDistanceField2D(d.map, d.cell_size)
+        N, B = 13, 3
+        st = TrajOptimizerSetting(D)
+        st.set_total_step(N); st.set_total_time(3.0); st.set_obs_check_inter(3); st.set_cost_sigma(0.1); st.set_epsilon(0.3)
+        st.set_conf_prior_model(1e-3); st.set_vel_prior_model(1e-3); st.set_Qc_model(np.eye(D)); st.setGaussNewton()
+        start = np.zeros((B, D))
+        end = np.linspace(0.3, 0.9, D)[None] + 0.2 * rng.normal(size=(B, D))
+        init = np.stack([initArmTrajStraightLine(start[b], end[b], N) for b in range(B)])
+        z = np.zeros((B, D))
+        p = problems.Problem(case, model, [d.origin_x, d.origin_y], d.cell_size, field, st, start, z, end, z.copy(), init)
+        traj = p.init + 0.1 * rng.normal(size=p.init.shape)
+    r, s, ro, so = _handles(engine, oracle, p)
+    ref = oracle.linearize(ro, so, p.setting, *_args(p), traj)
+    assert np.abs(ref[2]).max() > 0 and (np.abs(ref[0]).reshape(p.B, -1).max(axis=1) > 0).all()
+    got = {}
+    for form in ("1", "2", "4"):
+        monkeypatch.setenv("GPMP2MI_LIN_SPLIT", form)
+        got[form] = engine.linearize(r, s, p.setting, *_args(p), traj)
+        for x, y in zip(got[form][:3], ref[:3]):
+            np.testing.assert_allclose(x, y, atol=1e-9 * np.abs(y).max(), err_msg=f"form {form}")
+        np.testing.assert_allclose(got[form][3], ref[3], rtol=1e-9, err_msg=f"form {form}")
+    for form in ("2", "4"):
+        for x, y in zip(got[form][:3], got["1"][:3]):
+            np.testing.assert_allclose(x, y, atol=1e-12 * np.abs(y).max())
+
+
+def test_both_run_ahead_modes_of_the_gauss_newton_driver(engine, small_wam, monkeypatch):
+    """The host enqueues either the whole next pass or only its linearization before it looks at a pass count
+    (GPMP2MI_GN_LOOKAHEAD=pass / lin, api.hip: plan_run_impl): same kernels in the same order on the same data, so the
+    results are bit-identical; fixed-iteration runs (closing error pass) included."""
+    from copy import deepcopy
+    p = small_wam
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    for fixed in (0, 2):
+        st = deepcopy(p.setting)
+        st.fixed_iterations = fixed
+        res = {}
+        for mode in ("pass", "lin"):
+            monkeypatch.setenv("GPMP2MI_GN_LOOKAHEAD", mode)
+            res[mode] = engine.batch_optimize(r, s, st, *_args(p), p.init)
+        for k in ("traj", "iters", "status", "final_error"):
+            np.testing.assert_array_equal(res["pass"][k], res["lin"][k])
