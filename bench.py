@@ -147,10 +147,25 @@ def head_commit():
         return None
 
 
-def kernels_changed_since(commit, here):
-    """True when the kernel sources (gpmp2_amd/csrc) differ between `commit` (where a stored profile was taken) and this
-    tree; later commits that only touch docs, tests or scripts do not make a profile stale.  Without git (the GPU box
-    gets the tree without .git) only an identical commit id counts as unchanged."""
+def kernel_sources_digest():
+    """sha1 over the device sources (gpmp2_amd/csrc/*.hip and *.h without api.hip, the host driver); scripts/pmc_to_json.py
+    stores the same digest in the traffic profile it writes"""
+    import hashlib
+    h = hashlib.sha1()
+    src = os.path.join(ROOT, "gpmp2_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if (f.endswith(".hip") or f.endswith(".h")) and f != "api.hip":
+            h.update(f.encode())
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def kernels_changed_since(commit, here, digest=None):
+    """True when the kernel sources differ between the tree a stored profile was taken from and this one.  The profile
+    carries a digest of the device sources (exact, and it needs no git -- the GPU box gets the tree without .git); older
+    profiles only name their commit: then git decides where it is present, else only an identical commit id counts."""
+    if digest:
+        return digest != kernel_sources_digest()
     if not commit or commit == "unknown":
         return True
     if here and (commit.startswith(here) or here.startswith(commit)):
@@ -183,8 +198,8 @@ def pmc_traffic():
                 key = {"linearize_arm": "linearize"}.get(key, key)   # the fixed-base-arm form of the same pass stage
                 out[key] = out.get(key, 0.0) + v["hbm_bytes_per_launch_corrected"]
         if out:
-            return out, os.path.basename(f), d.get("commit")
-    return None, None, None
+            return out, os.path.basename(f), d.get("commit"), d.get("sources_digest")
+    return None, None, None, None
 
 
 def status_hist(status):
@@ -416,10 +431,10 @@ def main():
             achieved = bytes_per_launch / (pass_ms * 1e-3) / 1e9
             path_gbs = ALGO_BYTES_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e9
             path_tflops = ALGO_FLOP_PER_TRAJ_ITER * passes_local / (ms_per_step * 1e-3) / 1e12
-            tr, tr_src, tr_commit = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None, None)
+            tr, tr_src, tr_commit, tr_digest = pmc_traffic() if (args.workload == "restarts" and B == 64 and args.opt == "GN") else (None, None, None, None)
             traffic = sum(tr.get(k, 0.0) for k in per) if tr else None
             here = head_commit()
-            stale = bool(tr) and kernels_changed_since(tr_commit, here)
+            stale = bool(tr) and kernels_changed_since(tr_commit, here, tr_digest)
             if stale:
                 print(f"bench.py: the stored traffic profile {tr_src} was taken at commit {tr_commit}, this tree is at {here}: "
                       "roofline.traffic and the per-kernel own-bytes fractions describe that commit (re-run scripts/evidence.sh)",

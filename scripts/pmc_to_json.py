@@ -5,9 +5,25 @@ profiles/rNN_pmc_traffic.json: per kernel, mean KB per launch as reported and th
 usage: python scripts/pmc_to_json.py <fetch_dir> <write_dir> <out.json> [commit]"""
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_digest(root=ROOT):
+    """sha1 over the device sources (gpmp2_amd/csrc/*.hip and *.h, api.hip -- the host driver -- left out): what a stored
+    traffic profile is valid for.  bench.py computes the same digest of the tree it runs from."""
+    h = hashlib.sha1()
+    src = os.path.join(root, "gpmp2_amd", "csrc")
+    for f in sorted(os.listdir(src)):
+        if (f.endswith(".hip") or f.endswith(".h")) and f != "api.hip":
+            h.update(f.encode())
+            h.update(open(os.path.join(src, f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 
 def per_kernel(d, counter):
@@ -41,7 +57,7 @@ def main():
             "--no-cpu-baseline), averaged per launch over all launches incl. late passes with few active trajectories. "
             "Units: KB as reported; corrected = (2*FETCH_SIZE + WRITE_SIZE)*1024 per MI355X_MICROARCH.md 'HBM' "
             "(gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream; other widths uncalibrated).")
-    json.dump(dict(note=note, commit=commit, kernels=kernels), open(out, "w"), indent=1)
+    json.dump(dict(note=note, commit=commit, sources_digest=kernel_sources_digest(), kernels=kernels), open(out, "w"), indent=1)
     print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 2) for k, v in kernels.items()}))
 
 
