@@ -359,10 +359,13 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start);
 // linearize `traj` into record buffer `bufsel` of every (active) trajectory: the fused obstacle / GP-prior kernel,
 // then -- only for plans that carry extra factors -- the workspace / self-collision factor kernels on the support
 // states and their accumulation into the unary records
-static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st) {
+// dst / pass: fused finish (launch_linearize); the extra-factor kernels then run on the NEW states in dst
+static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st,
+                          double* dst = nullptr, int pass = 0) {
   const PlanParams& P = p->hp;
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st));
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st, dst, pass));
   if (!p->has_extras) return GPMP2MI_OK;
+  if (dst) traj = dst;
   const PlanExtras& ex = p->ex;
   const RobotDev& h = p->robot->h;
   const int M = P.B * (P.N + 1), D = P.D, L = h.nr_links, S = h.nr_spheres;
@@ -1066,6 +1069,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     const char* e = getenv("GPMP2MI_LIN_SPLIT");
     P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? (B <= 256 ? 4 : 2) : 1;
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) P.lin_split = e[0] - '0';
+    // (the four-wavefront form keeps the <= 24 states of a chunk in LDS: two or more sub-steps per interval)
+    if (P.lin_split == 4 && (robot->h.kind != GPMP2MI_ROBOT_ARM || s->obs_check_inter < 2)) P.lin_split = 2;
+    // fused finish of the Gauss-Newton fast path (k_linearize_arm); GPMP2MI_FUSED_FINISH=0: k_finish_step as before
+    const char* ff = getenv("GPMP2MI_FUSED_FINISH");
+    P.fuse_finish = (P.lin_split == 4 && P.split_back && !wide && !(ff && ff[0] == '0')) ? 1 : 0;
   }
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
@@ -1398,31 +1406,39 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
     // idle tail shrinks to one empty kernel.
     const char* ahead_env = getenv("GPMP2MI_GN_LOOKAHEAD");
     const bool ahead_lin = !(ahead_env && ahead_env[0] == 'p');
+    // Fused finish (P.fuse_finish): there is no k_finish_step; the linearization of pass k applies the step of pass k - 1
+    // itself, reading the states of pass k - 1 from one of the plan's two state buffers and writing those of pass k to
+    // the other -- cur / last swap roles every pass, the step kernel picks them by the parity of its pass number.
+    const bool fuse = P.fuse_finish != 0;
+    auto states_of = [&](int pass) -> double* { return (fuse && (pass & 1)) ? pb.last : pb.cur; };
+    auto enqueue_lin = [&](int pass) -> int {
+      p->timer.begin("linearize", st);
+      if (fuse && pass > 0) return plan_linearize(p, states_of(pass - 1), 0, pb.active, st, states_of(pass), pass);
+      return plan_linearize(p, pb.cur, 0, pb.active, st);
+    };
     auto enqueue_rest = [&](int pass) -> int {
       if (P.fixed_iters > 0 && pass == P.fixed_iters) {
         // closing pass of a fixed-iteration run: nothing is solved any more, only the error of the final values
         p->timer.begin("final_error", st);
-        G2_TRY(launch_error_parts(P, pb, pb.cur, 0, pb.active, st));
+        G2_TRY(launch_error_parts(P, pb, states_of(pass), 0, pb.active, st));
       } else {
         p->timer.begin("assemble", st);
-        G2_TRY(launch_assemble(P, pb, pb.cur, 0, pb.active, st));
+        G2_TRY(launch_assemble(P, pb, states_of(pass), 0, pb.active, st));
       }
       p->timer.begin("gn_step_cr", st);
       G2_TRY(launch_gn_step_cr(P, pb, pass, st));
-      if (P.split_back) {
+      if (P.split_back && !fuse) {
         p->timer.begin("finish_step", st);
         G2_TRY(launch_finish_step(P, pb, pass, st));
       }
       return GPMP2MI_OK;
     };
     if (ahead_lin) {
-      p->timer.begin("linearize", st);
-      G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
+      G2_TRY(enqueue_lin(0));
       for (int pass = 0; pass < max_pass; pass++) {
         G2_TRY(enqueue_rest(pass));
         if (pass + 1 == max_pass) break;
-        p->timer.begin("linearize", st);
-        G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));   // of pass + 1, ahead of the count
+        G2_TRY(enqueue_lin(pass + 1));   // ahead of the count
         p->timer.close(st);
         int cnt = 0;
         G2_TRY(wait_pass_count(p, pass, st, &cnt));
@@ -1431,8 +1447,7 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
       p->timer.close(st);
     } else {
       for (int pass = 0; pass < max_pass; pass++) {
-        p->timer.begin("linearize", st);
-        G2_TRY(plan_linearize(p, pb.cur, 0, pb.active, st));
+        G2_TRY(enqueue_lin(pass));
         G2_TRY(enqueue_rest(pass));
         p->timer.close(st);
         if (pass >= 1) {

@@ -290,42 +290,6 @@ int launch_assemble(const PlanParams& hp, const PlanBuffers& pb, const double* t
   return GPMP2MI_OK;
 }
 
-// sum over the 16 lanes of a DPP row, result in every lane of the row
-__device__ __forceinline__ double row_sum16(double v) {
-#if G2_SUM_DPP
-  return row_sum16_dpp(v);
-#else
-#pragma unroll
-  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
-  return v;
-#endif
-}
-
-// x_j = V^T (y - Wl x_l - Wr x_r); xl / xr = neighbour solutions at this lane's column
-template <int n>
-__device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, const Tile& V, double xl,
-                                               double xr, int lane) {
-  const int c = lane & 15;
-  double t[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    double v;
-    if (c == RHSCOL) v = -Wl.r[k];                     // -y (same in both tiles)
-    else v = (c < n) ? fma(Wl.r[k], xl, Wr.r[k] * xr) : 0.0;
-    t[k] = -row_sum16(v);
-  }
-  double x = 0.0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) x = fma(V.r[k], t[k], x);
-#if G2_SUM_DPP
-  return sum_rows(x);
-#else
-  x += __shfl_xor(x, 16, 64);
-  x += __shfl_xor(x, 32, 64);
-  return x;
-#endif
-}
-
 // =============================================================================== GN step (CR)
 constexpr int FIN_BLOCKS = 8;   // blocks per workgroup of k_finish_step / k_finish_trial (levels 4, 2, 1 run there)
 #ifndef G2_CR_WAVES
@@ -436,14 +400,6 @@ __device__ __forceinline__ bool cr_forward(const PlanBuffers& pb, int b, int N, 
   return ok;
 }
 
-// The third factor tile of a block eliminated at level h: k_assemble (level 1, and level 2 when N >= 2) stores V, the
-// levels the step kernels run themselves store Vt (see tile_load_transposed)
-template <int n>
-__device__ __forceinline__ Tile load_v(const double* p, int h, int N, int lane) {
-  const int h0 = (N >= 2) ? 4 : 2;   // first level of cr_forward
-  return (h >= h0) ? tile_load_transposed<n>(p, lane) : tile_load_rows<n>(p, lane);
-}
-
 // Back-substitution down the same tree, levels hfinal .. hmin; leaves x of every block it reaches in
 // xs[(N+1)][16] (LDS).
 template <int n>
@@ -499,8 +455,11 @@ __device__ __forceinline__ void gn_step_body(const PlanParams& P, const PlanBuff
   if (!pb.active[b]) return;
   const int N = P.N;
   const size_t tsz = (size_t)(N + 1) * n;
-  double* cur = pb.cur + b * tsz;
-  double* last = pb.last + b * tsz;
+  // fused finish (plan.h: fuse_finish): the states of pass k live in pb.cur for even k, pb.last for odd k, and the other
+  // buffer holds the states the last step started from
+  const bool odd = P.fuse_finish && (pass & 1);
+  double* cur = (odd ? pb.last : pb.cur) + b * tsz;
+  double* last = (odd ? pb.cur : pb.last) + b * tsz;
   double* result = pb.result + b * tsz;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* xs = smem;                       // [N+1][16] solution of each block

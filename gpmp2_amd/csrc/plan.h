@@ -22,6 +22,8 @@ struct PlanParams {
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
   int spart_groups;                    // workgroups per trajectory of k_finish_trial(_wide)
   int wide_h0;                         // wide blocks: first forward level k_solve_step_wide runs itself (levels below: k_cr_level_wide)
+  int fuse_finish;                     // GN fast path: levels 4, 2, 1 of the back-substitution and the retract run at the head of the
+                                       // NEXT pass's k_linearize_arm (no k_finish_step); the state buffers cur / last swap roles every pass
   double eps, obs_w, delta_t;          // obs_w = 1 / cost_sigma^2
   double conf_prior_w, vel_prior_w;    // 1 / sigma^2
   double vdyn_w;                       // 1 / dynamics_sigma^2 or 0
@@ -143,7 +145,7 @@ __host__ __device__ inline double* gpu_of(const PlanBuffers& pb, int which_b, in
 
 int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
                      const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
-                     const int* active, hipStream_t st);
+                     const int* active, hipStream_t st, double* dst = nullptr, int pass = 0);
 int launch_extra_accumulate(const PlanParams& hp, const PlanBuffers& pb, const PlanExtras& ex, int L, int S, int bufsel,
                             const int* active, hipStream_t st);
 int launch_set_mode(const PlanBuffers& pb, int opt_type, int fixed_iters, hipStream_t st);

@@ -302,11 +302,19 @@ __global__ __launch_bounds__(64 * NSPLIT, KIND == GPMP2MI_ROBOT_ARM ? 2 : 1) voi
 // VGPRs, two wavefronts per SIMD) the dependent chain of a wavefront is sin/cos of two joints + 4 spheres instead of
 // 7 joints + 8 spheres, and 168 VGPRs leave room for three wavefronts per SIMD: 640 workgroups x 4 wavefronts of the
 // 64-restart batch are resident at once.
+// Fused finish (Gauss-Newton fast path, `dst` != nullptr): the kernel first APPLIES the step the previous pass solved.  The
+// step kernel left the solution of the blocks that are multiples of 8 (pb.xg); every workgroup here back-substitutes levels
+// 4, 2, 1 for the 12 - 18 states its 64 points touch -- only the blocks those states need, found with bit masks over a window
+// of <= 40 blocks; what k_finish_step did chip-wide in a launch of its own (7 - 8 us) --, adds the step to the states it
+// reads from `traj` (the buffer of the previous pass, which nobody writes during this kernel), keeps the new states in
+// LDS for its own points and writes those whose unary point lies in its chunk to `dst`.  The two state buffers of a
+// plan (cur / last) swap roles from pass to pass, so `last` is simply the buffer the step started from.
 template <int AD, int SDIM, int NW>
 __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __restrict__ Rg, SdfDev sdf,
                                                                const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                                const double* __restrict__ traj, int bufsel,
-                                                               const int* __restrict__ active) {
+                                                               const int* __restrict__ active, double* __restrict__ dst,
+                                                               int pass) {
   static_assert(NW == 2 || NW == 4, "tree reduction below");
   constexpr int D = AD, n = 2 * D, NG = D * (D + 1) / 2, RV = NG + D + 1;
   constexpr int FR = 9;                                  // doubles per lane and link: c0, c2, t
@@ -340,7 +348,65 @@ __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __
     j = t - (i - 1) * (I + 1);
   }
   const bool unary = (j == I);
-  const double* z1 = traj + ((size_t)b * (N + 1) + i) * n;          // state i
+  // ---- the states this workgroup reads: [s0, s1]; through LDS (zn), with the pending step applied in the fused form
+  constexpr int FXS = 40, ZNS = 24;
+  double (*fx)[16] = reinterpret_cast<double (*)[16]>(&buf[0][0]);   // step of the blocks w0 .. w0 + 39 (buf is not in use yet)
+  static_assert(FXS * 16 <= ROWS * 64, "the step window lives in the frame buffer");
+  __shared__ double zn[ZNS][n];       // states s0 .. s0 + 23
+  const int p_lo = chunk * 64, p_hi = min(p_lo + 63, P.P - 1);
+  auto state_of = [&](int pt) { return pt == 0 ? 0 : 1 + (pt - 1) / (I + 1); };
+  const int s1 = state_of(p_hi), s0 = max(0, state_of(p_lo) - 1), ns = s1 - s0 + 1;   // ns <= ZNS: launch_linearize checks
+  const bool apply = dst != nullptr && pb.stepped[b] == pass;
+  if (apply) {
+    const double* fac = pb.fac + (size_t)b * (N + 1) * 3 * TILE_DBL;
+    const double* xg = pb.xg + (size_t)b * (N + 1) * 16;
+    const int w0 = s0 & ~7, c = lane & 15, g = lane >> 4;
+    using u64 = unsigned long long;
+    auto bits = [](int lo, int hi) -> u64 { return (hi < lo) ? 0ull : ((~0ull >> (63 - (hi - lo))) << lo); };   // [lo, hi], hi <= 63
+    const u64 valid = bits(0, min(N - w0, FXS - 1)), inr = bits(s0 - w0, s1 - w0);
+    const u64 L1 = 0xAAAAAAAAAAAAAAAAull, L2 = 0x4444444444444444ull, L4 = 0x1010101010101010ull, L8 = 0x0101010101010101ull;
+    // a block of level h needs its neighbours at distance h, which belong to higher levels
+    const u64 need1 = inr & L1 & valid, nb1 = (need1 << 1) | (need1 >> 1);
+    const u64 need2 = (inr | nb1) & L2 & valid, nb2 = (need2 << 2) | (need2 >> 2);
+    const u64 need4 = (inr | nb1 | nb2) & L4 & valid, nb4 = (need4 << 4) | (need4 >> 4);
+    const u64 need8 = (inr | nb1 | nb2 | nb4) & L8 & valid;
+    // multiples of 8: solved by the step kernel
+    for (u64 m = need8; m; m &= m - 1) {
+      const int k = __builtin_ctzll(m);
+      if (wv == ((k >> 3) & (NW - 1)) && lane < 16) fx[k][lane] = xg[(size_t)(w0 + k) * 16 + lane];
+    }
+    __syncthreads();
+    // Task t of a level (the t-th needed block) belongs to wavefront t % NW.  (Requesting the factor tiles ahead -- all twelve
+    // of a wavefront at once, or one level ahead -- was slower: 21.0 / 20.2 against 19.5 us; 2 560 wavefronts x 21 KB.)
+    auto level = [&](u64 need, int h) {
+      int t = 0;
+      for (u64 m = need; m; m &= m - 1, t++) {
+        if ((t & (NW - 1)) != wv) continue;
+        const int k = __builtin_ctzll(m), jb = w0 + k;
+        const double* f = fac + (size_t)jb * 3 * TILE_DBL;
+        const Tile Wl = tile_load_rows<n>(f, lane), Wr = tile_load_rows<n>(f + TILE_DBL, lane);
+        const Tile V = load_v<n>(f + 2 * TILE_DBL, h, N, lane);
+        const double xl = (k - h >= 0) ? fx[k - h][c] : 0.0;          // (k - h < 0 cannot happen: w0 is a multiple of 8)
+        const double xr = (jb + h <= N) ? fx[k + h][c] : 0.0;
+        const double x = cr_backsolve<n>(Wl, Wr, V, xl, xr, lane);
+        if (g == 0) fx[k][c] = (c < n) ? x : 0.0;
+      }
+      __syncthreads();
+    };
+    level(need4, 4);
+    level(need2, 2);
+    level(need1, 1);
+  }
+  for (int e = threadIdx.x; e < ns * n; e += 64 * NW) {
+    const int t = e / n, rho = e - t * n, st = s0 + t;
+    double z = traj[((size_t)b * (N + 1) + st) * n + rho];
+    if (apply) z += fx[st - (s0 & ~7)][rho];      // Values::retract of a vector-valued state
+    zn[t][rho] = z;
+    const int pu = st * (I + 1);                  // the state's unary evaluation point: its owner writes the state
+    if (dst != nullptr && pu >= p_lo && pu <= p_lo + 63) dst[((size_t)b * (N + 1) + st) * n + rho] = z;
+  }
+  __syncthreads();
+  const double* z1 = &zn[i - s0][0];                                 // state i
   const double* z0 = (i > 0) ? z1 - n : z1;                          // state i-1 (only used if i > 0)
   {
     double q[D];
@@ -520,9 +586,19 @@ __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __
   G2_LSTAMP(15);
 }
 
+// dst / pass: fused finish of the Gauss-Newton fast path (k_linearize_arm; only with hp.fuse_finish): apply the step of
+// pass - 1 to the states in `traj` and write the new states to `dst`; dst = nullptr: linearize `traj` as it is
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
                      const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
-                     hipStream_t st) {
+                     hipStream_t st, double* dst, int pass) {
+  if (dst != nullptr && !(hp.fuse_finish && hp.lin_split == 4 && h.kind == GPMP2MI_ROBOT_ARM)) {
+    set_error("fused finish asked of a plan that was not set up for it");
+    return GPMP2MI_ERR_INVALID;
+  }
+  if (hp.lin_split == 4 && 63 / (hp.I + 1) + 3 > 24) {   // states per chunk kept in LDS by k_linearize_arm (ZNS)
+    set_error("the four-wavefront linearization needs obs_check_inter >= 2");
+    return GPMP2MI_ERR_INVALID;
+  }
   // One lane per evaluation point; fixed-base arms split the spheres of a point over the two wavefronts of a
   // workgroup (NSPLIT = 2, see the kernel).  A variant that kept 4-8 SDF cells in flight per lane was no faster
   // (DESIGN.md section 4).
@@ -530,9 +606,9 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   if (hp.lin_split == 4 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(256);
     if (sdf.dim == 3) {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 3, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 3, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass)));
     } else {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 2, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 2, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass)));
     }
   } else if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(128);

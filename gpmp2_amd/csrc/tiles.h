@@ -483,4 +483,51 @@ __device__ __forceinline__ bool chain_solve(int nblk, BlockSrc&& next_block, dou
   return ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// back-substitution of one block of the cyclic reduction (cr_kernels.hip: cr_backward, k_finish_step; plan_kernels.hip:
+// the fused finish of k_linearize_arm)
+// sum over the 16 lanes of a DPP row, result in every lane of the row
+__device__ __forceinline__ double row_sum16(double v) {
+#if G2_SUM_DPP
+  return row_sum16_dpp(v);
+#else
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o, 64);
+  return v;
+#endif
+}
+
+// x_j = V^T (y - Wl x_l - Wr x_r); xl / xr = neighbour solutions at this lane's column
+template <int n>
+__device__ __forceinline__ double cr_backsolve(const Tile& Wl, const Tile& Wr, const Tile& V, double xl,
+                                               double xr, int lane) {
+  const int c = lane & 15;
+  double t[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double v;
+    if (c == RHSCOL) v = -Wl.r[k];                     // -y (same in both tiles)
+    else v = (c < n) ? fma(Wl.r[k], xl, Wr.r[k] * xr) : 0.0;
+    t[k] = -row_sum16(v);
+  }
+  double x = 0.0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) x = fma(V.r[k], t[k], x);
+#if G2_SUM_DPP
+  return sum_rows(x);
+#else
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+#endif
+}
+
+// The third factor tile of a block eliminated at level h: k_assemble (level 1, and level 2 when N >= 2) stores V, the
+// levels the step kernels run themselves store Vt (see tile_load_transposed)
+template <int n>
+__device__ __forceinline__ Tile load_v(const double* p, int h, int N, int lane) {
+  const int h0 = (N >= 2) ? 4 : 2;   // first level of cr_forward
+  return (h >= h0) ? tile_load_transposed<n>(p, lane) : tile_load_rows<n>(p, lane);
+}
+
 }  // namespace g2

@@ -691,3 +691,29 @@ def test_both_run_ahead_modes_of_the_gauss_newton_driver(engine, small_wam, monk
             res[mode] = engine.batch_optimize(r, s, st, *_args(p), p.init)
         for k in ("traj", "iters", "status", "final_error"):
             np.testing.assert_array_equal(res["pass"][k], res["lin"][k])
+
+
+@pytest.mark.parametrize("N,inter,fixed", [(100, 5, 0), (37, 2, 0), (64, 3, 3), (23, 4, 0), (16, 2, 2)])
+def test_fused_finish_is_the_finish_kernel(engine, oracle, monkeypatch, N, inter, fixed):
+    """Gauss-Newton fast path of fixed-base arms: levels 4, 2, 1 of the back-substitution and the retract run either in
+    k_finish_step or at the head of the next pass's k_linearize_arm (GPMP2MI_FUSED_FINISH=0 / default; the two state
+    buffers then swap roles every pass).  Same tiles, same arithmetic: the results are bit-identical -- trajectories,
+    iteration counts, status (including the rolled-back ones, which return the buffer the last step started from) --
+    and they meet the oracle.  Sizes: the headline's, N not a multiple of 8, the smallest sub-step count the fused form
+    takes, a fixed-iteration run (closing error pass), the smallest N with a split back-substitution."""
+    from copy import deepcopy
+    p = problems.wam_restarts(B=6, total_step=N, obs_check_inter=inter, opt="GN", sdf="40")
+    st = deepcopy(p.setting)
+    st.fixed_iterations = fixed
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GPMP2MI_FUSED_FINISH", mode)
+        res[mode] = engine.batch_optimize(r, s, st, *_args(p), p.init)
+    for k in ("traj", "iters", "status", "final_error", "error_trace"):
+        np.testing.assert_array_equal(res["0"][k], res["1"][k], err_msg=k)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    if fixed == 0:
+        ref = oracle.batch_optimize(ro, so, st, *_args(p), p.init)
+        assert list(res["1"]["iters"]) == list(ref["iters"]) and list(res["1"]["status"]) == list(ref["status"])
+        np.testing.assert_allclose(res["1"]["traj"], ref["traj"], atol=1e-6)
