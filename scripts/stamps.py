@@ -38,7 +38,7 @@ for b in (0, 33):
     e._ck(e.lib.gpmp2mi_plan_debug_stamps(pl.h.ptr, b, out))
     raw = np.array(list(out), dtype=np.float64)
     print(f"trajectory {b}")
-    print("   linearize wavefront 0 (chunk 1), k_linearize_arm: loads + interpolation + sin/cos + barrier | chain walk (wavefront 0) + barrier | "
+    print("   linearize wavefront 0 (chunk 1), k_linearize_arm: fused finish (levels 4, 2, 1 of the previous step for its states) + state loads + interpolation + sin/cos + barrier | chain walk (wavefront 0) + barrier | "
           "its 4 spheres | wait for the others + tree sum | record store | (gp prior: last wavefront)", d(raw[48:64]))
     print("   assemble wave i=1 (odd block): stage / build / misc / eliminate / store", d(raw[32:38]))
     print("   build_tiles i=1: owner rows / constants + unary / sub-step loop / replanner priors + shuffles", d(raw[24:29]))
