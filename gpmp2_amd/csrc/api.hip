@@ -361,9 +361,9 @@ static int plan_run(gpmp2mi_plan* p, hipStream_t st, const double* start);
 // states and their accumulation into the unary records
 // dst / pass: fused finish (launch_linearize); the extra-factor kernels then run on the NEW states in dst
 static int plan_linearize(gpmp2mi_plan* p, const double* traj, int bufsel, const int* active, hipStream_t st,
-                          double* dst = nullptr, int pass = 0) {
+                          double* dst = nullptr, int pass = 0, bool trial = false) {
   const PlanParams& P = p->hp;
-  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st, dst, pass));
+  G2_TRY(launch_linearize(p->robot->h, p->robot->d, p->sdf->h, P, p->pb, traj, bufsel, active, st, dst, pass, trial));
   if (!p->has_extras) return GPMP2MI_OK;
   if (dst) traj = dst;
   const PlanExtras& ex = p->ex;
@@ -1063,17 +1063,21 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   P.end_conf_prior_off = o.end_conf_prior_off ? 1 : 0;
   {
     // sphere-split linearization for fixed-base arms: four wavefronts per 64 points sharing one walk of the chain
-    // (k_linearize_arm) up to 256 trajectories, two wavefronts that each walk it (k_linearize NSPLIT = 2) above --
-    // measured (scripts/probes/split_sweep.sh): 14.4 / 16.8 / 22.5 / 35.5 / 59.3 us against 17.6 / 18.7 / 24.2 / 35.6 /
-    // 58.1 us at 32 / 64 / 128 / 256 / 512 trajectories.  GPMP2MI_LIN_SPLIT=1 / 2 / 4 forces a form.
+    // (k_linearize_arm), or two wavefronts that each walk it (k_linearize NSPLIT = 2).  Alone, the four-wavefront form wins
+    // up to 256 trajectories (scripts/probes/split_sweep.sh, round 3: 14.4 / 16.8 / 22.5 / 35.5 / 59.3 us against 17.6 / 18.7 /
+    // 24.2 / 35.6 / 58.1 us at 32 / 64 / 128 / 256 / 512); with the fused finish, which only it has, it wins the Gauss-Newton
+    // pass at every size (195.3 / 226.9 / 224.8 k against 193.4 / 225.1 / 218.6 k traj/s at 256 / 512 / 1 024).  So: Gauss-Newton
+    // plans always, LM / Dogleg plans up to 256 trajectories.  GPMP2MI_LIN_SPLIT=1 / 2 / 4 forces a form.
     const char* e = getenv("GPMP2MI_LIN_SPLIT");
-    P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? (B <= 256 ? 4 : 2) : 1;
+    const bool four = B <= 256 || s->opt_type == GPMP2MI_OPT_GAUSS_NEWTON;
+    P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? (four ? 4 : 2) : 1;
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) P.lin_split = e[0] - '0';
     // (the four-wavefront form keeps the <= 24 states of a chunk in LDS: two or more sub-steps per interval)
     if (P.lin_split == 4 && (robot->h.kind != GPMP2MI_ROBOT_ARM || s->obs_check_inter < 2)) P.lin_split = 2;
     // fused finish of the Gauss-Newton fast path (k_linearize_arm); GPMP2MI_FUSED_FINISH=0: k_finish_step as before
     const char* ff = getenv("GPMP2MI_FUSED_FINISH");
     P.fuse_finish = (P.lin_split == 4 && P.split_back && !wide && !(ff && ff[0] == '0')) ? 1 : 0;
+    if (P.fuse_finish) P.spart_groups = P.Ppad / 64;   // the trial-step shares then come per chunk of k_linearize_arm
   }
   P.eps = s->epsilon;
   P.obs_w = 1.0 / (s->cost_sigma * s->cost_sigma);
@@ -1206,7 +1210,7 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
   G2_TRY(plan_alloc(p.get(), &pb.scal, (size_t)B * SC_COUNT));
   G2_TRY(plan_alloc(p.get(), &pb.which, B));
   G2_TRY(plan_alloc(p.get(), &pb.stepped, B));
-  G2_TRY(plan_alloc(p.get(), &pb.spart, (size_t)B * ((P.N + 4) / 4) * 3));
+  G2_TRY(plan_alloc(p.get(), &pb.spart, (size_t)B * std::max((P.N + 4) / 4, P.Ppad / 64) * 3));
   G2_TRY(plan_alloc(p.get(), &pb.xg, (size_t)B * (P.N + 1) * (wide ? 32 : 16)));
   if (dense_path) {   // dense normal equations + the factors of the dense cyclic reduction
     G2_TRY(plan_alloc(p.get(), &pb.wHd, (size_t)B * (P.N + 1) * P.n * P.n));
@@ -1501,13 +1505,18 @@ static int plan_run_impl(gpmp2mi_plan* p, hipStream_t st, const double* start) {
         }
         p->timer.begin("solve_step", st);
         G2_TRY(launch_solve_step(P, pb, st));
-        if (P.split_back && P.opt_type != GPMP2MI_OPT_DOGLEG) {   // LM / GN: levels 2, 1, step and trial point chip-wide
+        if (P.split_back && P.opt_type != GPMP2MI_OPT_DOGLEG && !P.fuse_finish) {   // LM / GN: levels 2, 1, step and trial point chip-wide
           p->timer.begin("finish_trial", st);
           G2_TRY(launch_finish_trial(P, pb, st));
         }
       }
       p->timer.begin("linearize", st);
-      G2_TRY(plan_linearize(p, pb.trial, 1, pb.active, st));
+      if (!P.wide && P.split_back && P.opt_type != GPMP2MI_OPT_DOGLEG && P.fuse_finish) {
+        // fused finish: the linearization forms the trial point cur (+) delta itself (k_linearize_arm, `trial`)
+        G2_TRY(plan_linearize(p, pb.cur, 1, pb.active, st, pb.trial, 1, true));
+      } else {
+        G2_TRY(plan_linearize(p, pb.trial, 1, pb.active, st));
+      }
       p->timer.begin("decide", st);
       G2_TRY(launch_decide(P, pb, pass, false, st));
       p->timer.close(st);

@@ -20,7 +20,8 @@ struct PlanParams {
   int end_conf_prior_off;              // 1: no PriorFactor on x_N (a goal / workspace factor stands in)
   int wide;                            // 2 dof > 15: blocks wider than one tile (2x2-tile kernels of wide_cr.h, or the dense path of dense_kernels.hip)
   int split_back;                      // GN: back-substitution levels 1, 2 and the retract run in k_finish_step
-  int spart_groups;                    // workgroups per trajectory of k_finish_trial(_wide)
+  int spart_groups;                    // shares per trajectory in pb.spart: workgroups of k_finish_trial(_wide), or the chunks of
+                                       // k_linearize_arm when it applies the trial step itself (fuse_finish)
   int wide_h0;                         // wide blocks: first forward level k_solve_step_wide runs itself (levels below: k_cr_level_wide)
   int fuse_finish;                     // GN fast path: levels 4, 2, 1 of the back-substitution and the retract run at the head of the
                                        // NEXT pass's k_linearize_arm (no k_finish_step); the state buffers cur / last swap roles every pass
@@ -145,7 +146,7 @@ __host__ __device__ inline double* gpu_of(const PlanBuffers& pb, int which_b, in
 
 int launch_linearize(const RobotDev& hrobot, const RobotDev* robot, const SdfDev& sdf,
                      const PlanParams& hp, const PlanBuffers& pb, const double* traj, int bufsel,
-                     const int* active, hipStream_t st, double* dst = nullptr, int pass = 0);
+                     const int* active, hipStream_t st, double* dst = nullptr, int pass = 0, bool trial = false);
 int launch_extra_accumulate(const PlanParams& hp, const PlanBuffers& pb, const PlanExtras& ex, int L, int S, int bufsel,
                             const int* active, hipStream_t st);
 int launch_set_mode(const PlanBuffers& pb, int opt_type, int fixed_iters, hipStream_t st);

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __
                                                                const PlanParams* __restrict__ pp, PlanBuffers pb,
                                                                const double* __restrict__ traj, int bufsel,
                                                                const int* __restrict__ active, double* __restrict__ dst,
-                                                               int pass) {
+                                                               int pass, int trial) {
   static_assert(NW == 2 || NW == 4, "tree reduction below");
   constexpr int D = AD, n = 2 * D, NG = D * (D + 1) / 2, RV = NG + D + 1;
   constexpr int FR = 9;                                  // doubles per lane and link: c0, c2, t
@@ -397,13 +397,45 @@ __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __
     level(need2, 2);
     level(need1, 1);
   }
+  // trial-step path (`trial`): dst is the trial point, the step itself goes to pb.delta, and the workgroup leaves its share
+  // of g.delta, |delta|^2, |g|^2 over the states it owns in pb.spart for k_decide (what k_finish_trial did per group of 8)
+  double s_gd = 0.0, s_dd = 0.0, s_gg = 0.0;
   for (int e = threadIdx.x; e < ns * n; e += 64 * NW) {
     const int t = e / n, rho = e - t * n, st = s0 + t;
-    double z = traj[((size_t)b * (N + 1) + st) * n + rho];
-    if (apply) z += fx[st - (s0 & ~7)][rho];      // Values::retract of a vector-valued state
+    const size_t k = ((size_t)b * (N + 1) + st) * n + rho;
+    double z = traj[k];
+    const double x = apply ? fx[st - (s0 & ~7)][rho] : 0.0;
+    z += x;                                       // Values::retract of a vector-valued state
     zn[t][rho] = z;
     const int pu = st * (I + 1);                  // the state's unary evaluation point: its owner writes the state
-    if (dst != nullptr && pu >= p_lo && pu <= p_lo + 63) dst[((size_t)b * (N + 1) + st) * n + rho] = z;
+    if (dst != nullptr && pu >= p_lo && pu <= p_lo + 63) {
+      dst[k] = z;
+      if (trial && apply) {
+        const double gk = pb.gvec[((size_t)b * (N + 1) + st) * 16 + rho];
+        pb.delta[k] = x;
+        s_gd = fma(gk, x, s_gd);
+        s_dd = fma(x, x, s_dd);
+        s_gg = fma(gk, gk, s_gg);
+      }
+    }
+  }
+  if (trial && apply) {   // fixed order: lanes (wave_sum), then wavefronts 0 .. NW - 1
+    __shared__ double psum[NW][3];
+    s_gd = wave_sum(s_gd);
+    s_dd = wave_sum(s_dd);
+    s_gg = wave_sum(s_gg);
+    if (lane == 0) {
+      psum[wv][0] = s_gd;
+      psum[wv][1] = s_dd;
+      psum[wv][2] = s_gg;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      double a = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; w++) a += psum[w][threadIdx.x];
+      pb.spart[((size_t)b * nchunk + chunk) * 3 + threadIdx.x] = a;
+    }
   }
   __syncthreads();
   const double* z1 = &zn[i - s0][0];                                 // state i
@@ -590,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, 3) void k_linearize_arm(const RobotDev* __
 // pass - 1 to the states in `traj` and write the new states to `dst`; dst = nullptr: linearize `traj` as it is
 int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf, const PlanParams& hp,
                      const PlanBuffers& pb, const double* traj, int bufsel, const int* active,
-                     hipStream_t st, double* dst, int pass) {
+                     hipStream_t st, double* dst, int pass, bool trial) {
   if (dst != nullptr && !(hp.fuse_finish && hp.lin_split == 4 && h.kind == GPMP2MI_ROBOT_ARM)) {
     set_error("fused finish asked of a plan that was not set up for it");
     return GPMP2MI_ERR_INVALID;
@@ -606,9 +638,9 @@ int launch_linearize(const RobotDev& h, const RobotDev* robot, const SdfDev& sdf
   if (hp.lin_split == 4 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(256);
     if (sdf.dim == 3) {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 3, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 3, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass, trial ? 1 : 0)));
     } else {
-      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 2, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass)));
+      G2_DISPATCH_ROBOT_ARM_ONLY(h.arm_dof, (k_linearize_arm<AD_, 2, 4><<<grid, block, 0, st>>>(robot, sdf, pb.params, pb, traj, bufsel, active, dst, pass, trial ? 1 : 0)));
     }
   } else if (hp.lin_split == 2 && h.kind == GPMP2MI_ROBOT_ARM) {
     const dim3 block(128);

@@ -717,3 +717,22 @@ def test_fused_finish_is_the_finish_kernel(engine, oracle, monkeypatch, N, inter
         ref = oracle.batch_optimize(ro, so, st, *_args(p), p.init)
         assert list(res["1"]["iters"]) == list(ref["iters"]) and list(res["1"]["status"]) == list(ref["status"])
         np.testing.assert_allclose(res["1"]["traj"], ref["traj"], atol=1e-6)
+
+
+def test_fused_finish_of_the_trial_step_path(engine, oracle, monkeypatch):
+    """LM on a fixed-base arm: the trial point cur (+) delta and the step-control shares g.delta, |delta|^2, |g|^2 come either
+    from k_finish_trial (per group of 8 blocks) or from the head of the trial linearization (per chunk of 64 evaluation
+    points; GPMP2MI_FUSED_FINISH=0 / default).  The shares are summed in another grouping, so the two forms agree to
+    rounding, not bit for bit; both meet the oracle."""
+    p = problems.wam_restarts(B=6, total_step=37, obs_check_inter=3, opt="LM", sdf="40")
+    r, s = engine.robot(p.model), engine.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GPMP2MI_FUSED_FINISH", mode)
+        res[mode] = engine.batch_optimize(r, s, p.setting, *_args(p), p.init)
+    assert list(res["0"]["iters"]) == list(res["1"]["iters"]) and list(res["0"]["status"]) == list(res["1"]["status"])
+    np.testing.assert_allclose(res["0"]["traj"], res["1"]["traj"], atol=1e-9)
+    ro, so = oracle.robot(p.model), oracle.sdf(p.sdf_origin, p.sdf_cell, p.sdf_data)
+    ref = oracle.batch_optimize(ro, so, p.setting, *_args(p), p.init)
+    assert list(res["1"]["iters"]) == list(ref["iters"]) and list(res["1"]["status"]) == list(ref["status"])
+    np.testing.assert_allclose(res["1"]["traj"], ref["traj"], atol=1e-6)
