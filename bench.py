@@ -16,7 +16,8 @@ GPU), relays rank 0's JSON line and exits with the children's status.  Under an 
 (WORLD_SIZE set) the process is a rank.
 
 Prints ONE JSON line (see the driver contract): metric trajectories/sec, plus
-  roofline      -- whole Gauss-Newton pass (linearize + assemble + solve + finish), SURVEY.md 8(d)'s
+  roofline      -- whole Gauss-Newton pass (linearize + assemble + solve; the finish of a step is part of the next
+                   linearization for fixed-base arms, a kernel of its own otherwise), SURVEY.md 8(d)'s
                    638 048 algorithmic bytes per trajectory-iteration / the summed average launch
                    durations of the pass's kernels (HIP events on the launch stream, inside the
                    library) vs the 8 TB/s HBM peak; `path_frac` = the same bytes over the wall time of
