@@ -1066,10 +1066,11 @@ int gpmp2mi_plan_create(const gpmp2mi_robot* robot, const gpmp2mi_sdf* sdf, cons
     // (k_linearize_arm), or two wavefronts that each walk it (k_linearize NSPLIT = 2).  Alone, the four-wavefront form wins
     // up to 256 trajectories (scripts/probes/split_sweep.sh, round 3: 14.4 / 16.8 / 22.5 / 35.5 / 59.3 us against 17.6 / 18.7 /
     // 24.2 / 35.6 / 58.1 us at 32 / 64 / 128 / 256 / 512); with the fused finish, which only it has, it wins the Gauss-Newton
-    // pass at every size (195.3 / 226.9 / 224.8 k against 193.4 / 225.1 / 218.6 k traj/s at 256 / 512 / 1 024).  So: Gauss-Newton
-    // plans always, LM / Dogleg plans up to 256 trajectories.  GPMP2MI_LIN_SPLIT=1 / 2 / 4 forces a form.
+    // pass at every size (195.3 / 226.9 / 224.8 k against 193.4 / 225.1 / 218.6 k traj/s at 256 / 512 / 1 024), and the LM pass
+    // too, if barely (97.7 / 102.0 k against 96.6 / 101.3 k at 512 / 1 024).  So: Gauss-Newton and LM plans always, Dogleg plans
+    // (no fusion there) up to 256 trajectories.  GPMP2MI_LIN_SPLIT=1 / 2 / 4 forces a form.
     const char* e = getenv("GPMP2MI_LIN_SPLIT");
-    const bool four = B <= 256 || s->opt_type == GPMP2MI_OPT_GAUSS_NEWTON;
+    const bool four = B <= 256 || s->opt_type != GPMP2MI_OPT_DOGLEG;
     P.lin_split = (robot->h.kind == GPMP2MI_ROBOT_ARM && robot->h.nr_spheres >= 2) ? (four ? 4 : 2) : 1;
     if (e && (e[0] == '1' || e[0] == '2' || e[0] == '4')) P.lin_split = e[0] - '0';
     // (the four-wavefront form keeps the <= 24 states of a chunk in LDS: two or more sub-steps per interval)
